@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rng_uniform(seed, shape):
+    """Same generator as oracle/gen_golden.py (numpy PCG64: stable across versions)."""
+    return np.random.default_rng(seed).random(shape, dtype=np.float32)
+
+
+def smooth_erp(seed, B, C, H, W, k=31, passes=2):
+    """Seeded low-pass noise in [0,1]: the input class on which the 1e-3 abs parity
+    gate is strict.  Box filter, circular along longitude."""
+    x = np.random.default_rng(seed).random((B, C, H, W)).astype(np.float64)
+    r = k // 2
+    for _ in range(passes):
+        xp = np.concatenate([x[..., -r:], x, x[..., :r]], axis=-1)
+        cs = np.cumsum(np.concatenate([np.zeros_like(xp[..., :1]), xp], -1), -1)
+        x = (cs[..., k:] - cs[..., :-k]) / k
+        xp = np.concatenate([np.repeat(x[..., :1, :], r, -2), x, np.repeat(x[..., -1:, :], r, -2)], -2)
+        cs = np.cumsum(np.concatenate([np.zeros_like(xp[..., :1, :]), xp], -2), -2)
+        x = (cs[..., k:, :] - cs[..., :-k, :]) / k
+    x = (x - x.min()) / (x.max() - x.min())
+    return x.astype(np.float32)
+
+
+def assert_close_outliers(got, want, tol=1e-3, max_tol=1e-2, frac=1e-5, what=""):
+    """Parity gate for i.i.d.-noise inputs: |d| <= tol for all but a
+    fraction `frac` of the elements, and |d| <= max_tol everywhere.  fp32 coordinate
+    round-off next to the poles / at step predicates makes a handful of samples
+    differ between ANY two fp32 evaluations of the same geometry (the reference's
+    own CPU result depends on its libm), so a strict bound holds only on smooth inputs."""
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    d = np.abs(got - want)
+    n_bad = int((d > tol).sum())
+    allowed = int(np.ceil(frac * d.size))
+    assert n_bad <= allowed, f"{what}: {n_bad} of {d.size} elements differ by > {tol} (allowed {allowed}); max {d.max():.3e}"
+    assert d.max() <= max_tol, f"{what}: max |d| = {d.max():.3e} > {max_tol}"
+    return float(d.max()), n_bad

@@ -1,0 +1,117 @@
+"""CPU: pin the C oracle (oracle/omni_oracle.c) against golden vectors produced by the
+reference itself (oracle/gen_golden.py).  Tolerances are written here:
+
+  * pers2equi:  |d| <= 2e-4 everywhere (smooth in the inputs; predicates may flip only
+    at measure-zero coordinates)
+  * equi2pers on i.i.d. noise: |d| <= 1e-3 except <= 2e-5 of the samples (polar
+    ill-conditioning of lon), |d| <= 2e-2 everywhere
+  * xyz / uv / center_p: 1e-4 / 1e-4 / exact
+  * G5 tables: integer taps and masks identical except where the reference's own X,Y lie
+    within 1e-3 px of an integer / of the patch edge.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from _util import golden, GOLDEN, rng_uniform, assert_close_outliers
+
+
+@pytest.mark.parametrize("name", ["G1_equi2pers_n4", "G2_equi2pers_n6", "G2b_equi2pers_n3",
+                                  "G2b_equi2pers_n5", "G2c_equi2pers_rect"])
+def test_equi2pers_golden(name):
+    g = golden(name)
+    fov = tuple(float(v) for v in g["fov"]); P = tuple(int(v) for v in g["patch"])
+    pers, xyz, uv, cp = co.equi2pers(g["erp"], fov, int(g["nrows"]), P)
+    assert pers.shape == g["pers"].shape
+    assert_close_outliers(pers, g["pers"], tol=1e-3, max_tol=2e-2, frac=2e-5, what=name)
+    np.testing.assert_allclose(xyz, g["xyz"], atol=1e-4)
+    np.testing.assert_allclose(uv, g["uv"], atol=1e-4)
+    np.testing.assert_array_equal(cp, g["center_p"])
+
+
+@pytest.mark.parametrize("name", ["G3_pers2equi_n4", "G3b_pers2equi_n3", "G3b_pers2equi_n5",
+                                  "G4_pers2equi_n6", "G4b_pers2equi_fov"])
+def test_pers2equi_golden(name):
+    g = golden(name)
+    fov = tuple(float(v) for v in g["fov"]); P = g["pers"].shape[2]
+    H, W = (int(v) for v in g["erp_size"])
+    erp = co.pers2equi(g["pers"], fov, int(g["nrows"]), (P, P), (H, W))
+    np.testing.assert_allclose(erp, g["erp"], atol=2e-4, rtol=0)
+
+
+def test_pers2equi_n3_uncovered_pixels_are_zero():
+    """nrows=3 leaves ERP pixels no patch covers: the reference outputs exactly 0 there."""
+    g = golden("G3b_pers2equi_n3")
+    erp, cover = co.pers2equi(g["pers"], (80, 80), 3, (16, 16), (64, 128), want_cover=True)
+    assert (cover == 0).sum() > 0
+    assert (g["erp"][0, 0][cover == 0] == 0).all()
+    assert (erp[0, 0][cover == 0] == 0).all()
+
+
+@pytest.mark.parametrize("nrows", [3, 4, 5, 6])
+def test_pers2equi_tables_golden(nrows):
+    g = golden(f"G5_tables_n{nrows}")
+    P = int(g["patch"]); H, W = (int(v) for v in g["erp_size"])
+    t = co.pers2equi_tables((80, 80), nrows, (P, P), (H, W))
+    # predicates / taps may only differ where the reference's own weights show the
+    # coordinate sits within 1e-3 px of a cell or patch boundary
+    w_ref = g["w_list"]; valid = g["mask"] == 1
+    same_mask = t["mask"] == g["mask"]
+    assert same_mask.mean() > 0.9999
+    both = valid & (t["mask"] == 1)
+    for k in ("x0", "y0", "x1", "y1"):
+        diff = (t[k] != g[k]) & both
+        assert diff.sum() <= 2, (k, int(diff.sum()))
+    ok = both & (t["x0"] == g["x0"]) & (t["y0"] == g["y0"])
+    np.testing.assert_allclose(t["w_list"][ok], w_ref[ok], atol=5e-4)
+    # coverage statistics of SURVEY §8(a): every pixel covered for nrows 4/5/6
+    cover = g["mask"].sum(0)
+    if nrows != 3:
+        assert cover.min() >= 1
+    else:
+        assert (cover == 0).sum() > 0
+
+
+def test_known_answers_config1():
+    """G8: BASELINE config-1 scale (512x1024 -> 18 x 256^2) against the reference's sums
+    and strided sub-samples."""
+    g = golden("G8_config1")
+    ka = json.load(open(os.path.join(GOLDEN, "G8_config1.json")))
+    erp = rng_uniform(100, (1, 3, 512, 1024))
+    pers, xyz, uv, cp = co.equi2pers(erp, (80, 80), 4, (256, 256))
+    assert abs(pers.astype(np.float64).sum() - ka["pers_sum"]) < 0.5      # 3.5M samples
+    assert_close_outliers(pers[:, :, ::8, ::8, :], g["pers_sub"], tol=1e-3, max_tol=2e-2, frac=5e-5)
+    np.testing.assert_allclose(xyz[:, :, ::8, ::8], g["xyz_sub"], atol=1e-4)
+    np.testing.assert_allclose(uv[:, :, ::8, ::8], g["uv_sub"], atol=1e-4)
+    np.testing.assert_array_equal(cp, g["center_p"])
+    pin = rng_uniform(101, (1, 1, 256, 256, 18))
+    e = co.pers2equi(pin, (80, 80), 4, (256, 256), (512, 1024))
+    assert abs(e.astype(np.float64).sum() - ka["erp_sum"]) < 0.1
+    np.testing.assert_allclose(e[:, :, ::4, ::4], g["erp_sub"], atol=2e-4)
+    np.testing.assert_allclose(e[:, :, [0, 1, 255, 256, 510, 511], :], g["erp_rows"], atol=2e-4)
+
+
+def test_survey_known_answer_centres():
+    """center_p[0] = [-0.6667,-0.75], center_p[3] = [-0.8333,-0.25]; q7 nrows=3 mismatch."""
+    _, _, cp = co.patch_centers(4)
+    np.testing.assert_allclose(cp[0], [-2 / 3, -0.75], atol=1e-6)
+    np.testing.assert_allclose(cp[3], [-5 / 6, -0.25], atol=1e-6)
+    _, phi_a, _ = co.patch_centers(3, 0); _, phi_b, _ = co.patch_centers(3, 1)
+    assert abs(np.degrees(phi_a[0]) + 60) < 1e-4 and abs(np.degrees(phi_b[0]) + 59.6) < 1e-4
+    with pytest.raises(ValueError):
+        co.patch_centers(7)
+
+
+def test_partition_of_unity_and_constant_invariance():
+    """Property: blend weights are L1-normalised, so a constant patch tensor maps to the
+    same constant wherever at least one patch covers the pixel (SURVEY §4 ii)."""
+    pers = np.full((1, 1, 32, 32, 18), 3.25, np.float32)
+    e, cover = co.pers2equi(pers, (80, 80), 4, (32, 32), (64, 128), want_cover=True)
+    assert cover.min() >= 1
+    np.testing.assert_allclose(e, 3.25, rtol=1e-5)
+    erp = np.full((1, 2, 64, 128), 0.625, np.float32)
+    p, _, _, _ = co.equi2pers(erp, (80, 80), 4, (16, 16))
+    np.testing.assert_allclose(p, 0.625, rtol=1e-6)

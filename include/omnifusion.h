@@ -1,0 +1,116 @@
+/*
+ * omnifusion.h — C ABI of libomnifusion_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the reference's `equi_pers` hot path.  Every entry point is
+ * `extern "C"`, takes plain device pointers + sizes + a hipStream_t passed as void*,
+ * allocates nothing the caller can see, never synchronises the host and returns an
+ * int status (OMNI_OK == 0); omni_last_error() returns the thread-local message.
+ * The reference has no FFI of its own (it is pure Python on stock PyTorch ops), so
+ * each function cites the reference *Python* interface it replaces.
+ *
+ * Tensor layouts (all dense, row-major, last index fastest):
+ *   ERP image          [B, C, H, W]
+ *   patches, reference [B, C, ph, pw, N]   OMNI_LAYOUT_BCHWN  (N innermost,
+ *                      equi2pers_v3.py:112-113; what the public Python API returns)
+ *   patches, planar    [B, N, C, ph, pw]   OMNI_LAYOUT_BNCHW  (patch-major; what the
+ *                      model uses internally so that no N-innermost tensor is ever
+ *                      materialised between the sampler, the network and the blender)
+ *   patches, NHWC      [B, N, ph, pw, C]   OMNI_LAYOUT_BNHWC  (network activations)
+ */
+#ifndef OMNIFUSION_H_
+#define OMNIFUSION_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMNI_VERSION 100
+
+enum omni_status {
+    OMNI_OK = 0,
+    OMNI_ERR_INVALID = 1,   /* bad nrows / shape / layout / null pointer  -> Python ValueError  */
+    OMNI_ERR_HIP = 2,       /* a HIP runtime call failed                  -> Python RuntimeError */
+    OMNI_ERR_UNSUPPORTED = 3
+};
+
+enum omni_layout { OMNI_LAYOUT_BCHWN = 0, OMNI_LAYOUT_BNCHW = 1, OMNI_LAYOUT_BNHWC = 2 };
+enum omni_dtype { OMNI_F32 = 0, OMNI_F16 = 1 };
+
+typedef void* omni_stream_t;            /* hipStream_t */
+typedef struct omni_geometry omni_geometry_t;
+
+int omni_version(void);
+const char* omni_last_error(void);
+
+/* Number of patches for an nrows preset (3,4,5,6 -> 10,18,26,46), -1 otherwise.
+ * equi2pers_v3.py:32-47 / pers2equi_v3.py:36-51 (the reference raises
+ * UnboundLocalError for any other value). */
+int omni_num_patches(int nrows);
+
+/* Patch centres in [-1,1] (`center_p`, equi2pers_v3.py:81-82) written to HOST memory
+ * center_p[N*2]; `which` = 0 equi2pers table, 1 pers2equi table (nrows=3 differs). */
+int omni_patch_centers(int nrows, int which, float* center_p_host);
+
+/*
+ * Geometry handle: the constants of one (nrows, fov, patch size, ERP size) configuration
+ * resident on the current device — patch-centre trig, per-row/column trig of the ERP
+ * grid and the per-tile candidate-patch masks of pers2equi.  A few KB; replaces the
+ * reference's per-call CPU grid build + H2D (equi2pers_v3.py:24-109) and its 0.5 GB
+ * ./grid/<layer_name>.pth tables (pers2equi_v3.py:24-29,155-167).  The convenience
+ * entry points below look handles up in an internal per-device, mutex-protected cache,
+ * so callers that mirror the reference's free functions never see this type.
+ */
+int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_h, float fov_w,
+                         int ph, int pw, int H, int W, omni_stream_t stream);
+void omni_geometry_destroy(omni_geometry_t* g);
+void omni_geometry_cache_clear(void);
+
+/*
+ * equi2pers — replaces equi_pers/equi2pers_v3.py:20 `equi2pers(erp_img, fov, nrows, patch_size)`
+ * (grid build :24-109, F.grid_sample bilinear/border/align_corners=True :111, unfold+reshape
+ * :112-113).  erp [B,C,H,W] -> pers in `layout`.  dtype: OMNI_F32 or OMNI_F16 storage
+ * (arithmetic is fp32 either way).
+ */
+int omni_equi2pers(const void* erp, void* pers, int dtype, int B, int C, int H, int W,
+                   int ph, int pw, int nrows, float fov_h, float fov_w, int layout,
+                   omni_stream_t stream);
+
+/* The other three return values of equi2pers (equi2pers_v3.py:115-122): xyz [N,3,ph,pw]
+ * unit rays from the UNWRAPPED lon/lat, uv [N,2,ph,pw] (the reference's scrambled strip
+ * reshape), both fp32 device buffers; either may be NULL. */
+int omni_equi2pers_aux(float* xyz, float* uv, int ph, int pw, int nrows, float fov_h, float fov_w,
+                       omni_stream_t stream);
+
+/*
+ * pers2equi — replaces equi_pers/pers2equi_v3.py:16
+ * `pers2equi(pers_img, fov, nrows, patch_size, erp_size, layer_name)` (tables :109-152,
+ * gathers :174-177, mask/threshold/L1-normalise/blend :179-196).  pers in `layout` -> erp
+ * [B,C,H,W].  `layer_name` was only the reference's cache-file key and has no counterpart.
+ */
+int omni_pers2equi(const void* pers, void* erp, int dtype, int B, int C, int ph, int pw,
+                   int H, int W, int nrows, float fov_h, float fov_w, int layout,
+                   omni_stream_t stream);
+
+/*
+ * Fused confidence blend — replaces model/spherical_model.py:307-311 (two pers2equi calls +
+ * zero-safe division):  out = P(pred_w) / (P(conf) + 1e-8*[P(conf) <= 1e-8]),
+ * pred_w = relu(pred)*sigmoid(weight_pred), conf = sigmoid(weight_pred), both C=1 patch
+ * tensors in `layout`; out [B,1,H,W] fp32.
+ */
+int omni_pers2equi_conf(const void* pred_w, const void* conf, float* out, int dtype, int B,
+                        int ph, int pw, int H, int W, int nrows, float fov_h, float fov_w,
+                        int layout, omni_stream_t stream);
+
+/* Explicit-handle forms of the three operators (same semantics, no cache lookup). */
+int omni_equi2pers_g(const omni_geometry_t* g, const void* erp, void* pers, int dtype, int B, int C,
+                     int layout, omni_stream_t stream);
+int omni_pers2equi_g(const omni_geometry_t* g, const void* pers, void* erp, int dtype, int B, int C,
+                     int layout, omni_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNIFUSION_H_ */

@@ -1,0 +1,79 @@
+"""ctypes loader of libomnifusion_hip.so — the ONLY compute path of this package.
+
+There is no CPU / PyTorch fallback: if the HIP library is missing or fails to load,
+importing the operators raises (the product path must fail loudly, never silently run
+something else).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libomnifusion_hip.so")
+
+OMNI_OK, OMNI_ERR_INVALID, OMNI_ERR_HIP, OMNI_ERR_UNSUPPORTED = 0, 1, 2, 3
+LAYOUT_BCHWN, LAYOUT_BNCHW, LAYOUT_BNHWC = 0, 1, 2
+F32, F16 = 0, 1
+
+_lib = None
+
+
+class OmniLibraryMissing(ImportError):
+    pass
+
+
+# every symbol include/omnifusion.h declares (tests/test_boundary.py parses the header and
+# checks this list against it and against the built library)
+EXPORTS = [
+    "omni_version", "omni_last_error", "omni_num_patches", "omni_patch_centers",
+    "omni_geometry_create", "omni_geometry_destroy", "omni_geometry_cache_clear",
+    "omni_equi2pers", "omni_equi2pers_aux", "omni_pers2equi", "omni_pers2equi_conf",
+    "omni_equi2pers_g", "omni_pers2equi_g",
+]
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmniLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m omnifusion_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.omni_last_error.restype = ctypes.c_char_p
+    lib.omni_version.restype = ctypes.c_int
+    for name in EXPORTS:
+        getattr(lib, name)          # AttributeError here = header/library mismatch
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    """Map C-ABI status codes to the exceptions the Python boundary promises
+    (SURVEY.md §8b 'Errors'): ValueError for bad arguments, RuntimeError for HIP errors."""
+    if status == OMNI_OK:
+        return
+    msg = load().omni_last_error().decode(errors="replace")
+    if status == OMNI_ERR_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    if status == OMNI_ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise ValueError(f"unsupported dtype {t.dtype}: the HIP path stores float32 or float16")

@@ -1,0 +1,310 @@
+// omni_equi2pers.hip — ERP -> N tangent-plane patches (gfx950).
+//
+// Replaces /root/reference/equi_pers/equi2pers_v3.py:20-122:
+//   K1  CPU grid build + repeat(bs) + H2D (:24-109)        -> evaluated in-kernel, closed form
+//   K2  F.grid_sample(bilinear, border, align_corners=True) (:111) -> gather below
+//   K3  F.unfold + reshape to [B,C,ph,pw,N] (:112-113)      -> fused into the store (LDS transpose)
+//   K4  uv2xyz rays (:13-18,115-118), uv (:120-121)         -> omni_equi2pers_aux
+//   K5  dead erp_mask work (:49-74)                         -> dropped
+//
+// Geometry.  The reference evaluates (fp32)  rho=sqrt(x^2+y^2), c=atan(rho),
+//   lat = asin(cos c sin p1 + y sin c cos p1 / rho),
+//   lon = l0 + atan2(x sin c, rho cos p1 cos c - y sin p1 sin c)             (:95-100)
+// With sin c = rho/sqrt(1+rho^2), cos c = 1/sqrt(1+rho^2) this is identically
+//   lat = asin((sin p1 + y cos p1) / sqrt(1+x^2+y^2)),   lon = l0 + atan2(x, cos p1 - y sin p1)
+// which needs two transcendental calls instead of six, has no 0/0 at the patch centre
+// (reference quirk q4 only bites for odd patch sizes, where the reference's grid is NaN)
+// and differs from the reference's fp32 chain by coordinate round-off only (a few 1e-4 px
+// away from the poles; tests/ carry the tolerance).
+//
+// Memory behaviour: one thread owns one (or four consecutive) sample position(s) and loops
+// over all B*C image planes, so geometry is evaluated once and amortised; ERP reads are
+// 4-byte gathers with wave-level locality (a wave walks a short curve on the ERP), patch
+// writes are fully coalesced.  HBM-bound: algorithmic bytes B*C*(H*W + ph*pw*N)*sizeof(T).
+#include "omni_internal.h"
+
+namespace {
+
+struct E2PArgs {
+    const void* erp; void* pers;
+    int B, C, H, W, ph, pw;
+    float fovx, fovy;          // fov_w/360, fov_h/180  (equi2pers_v3.py:24)
+    float stepx, stepy;        // linspace(0,1,P) step (:29)
+    float sx_scale, sy_scale;  // (W-1)/2, (H-1)/2  (grid_sample align_corners=True)
+    PatchTab tab;
+};
+
+struct Tap {                    // one bilinear footprint on the ERP
+    int o00;                    // y0*W + x0
+    int dx, dy;                 // 1 / W, or 0 when the +1 tap is outside (masked to weight 0 by ATen)
+    float tx, ty;               // fractional offsets
+};
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float PI_2_F = 1.57079632679489661923f;
+
+__device__ __forceinline__ float lin01(int idx, int steps, float step)
+{
+    // torch.linspace(0, 1, steps)[idx] in fp32 (two-sided), equi2pers_v3.py:29
+    return (idx < (steps >> 1)) ? step * (float)idx : 1.0f - step * (float)(steps - 1 - idx);
+}
+
+// inverse gnomonic for sample (h, w) of patch n -> unwrapped lon, lat and the pieces xyz needs
+__device__ __forceinline__ void e2p_lonlat(const E2PArgs& a, int n, int h, int w,
+                                           float& lon, float& lat, float& x, float& q, float& t, float& inv)
+{
+    const float sw = lin01(w, a.pw, a.stepx), sh = lin01(h, a.ph, a.stepy);
+    x = ((sw * 2.0f - 1.0f) * PI_F) * a.fovx;                 // :86-89
+    const float y = ((sh * 2.0f - 1.0f) * PI_2_F) * a.fovy;
+    const float sp = a.tab.sphi[n], cp = a.tab.cphi[n];
+    q = cp - y * sp;
+    t = sp + y * cp;
+    inv = 1.0f / sqrtf(1.0f + x * x + y * y);
+    float sl = t * inv;
+    sl = fminf(1.0f, fmaxf(-1.0f, sl));
+    lat = asinf(sl);
+    lon = a.tab.lam0[n] + atan2f(x, q);
+}
+
+__device__ __forceinline__ void e2p_uv(float lon, float lat, float& u, float& v)
+{
+    v = lat / PI_2_F;                                          // :101
+    u = lon / PI_F;                                            // :102
+    if (u > 1.0f) u -= 2.0f;                                   // :103
+    if (u < -1.0f) u += 2.0f;                                  // :104
+}
+
+__device__ __forceinline__ Tap e2p_tap(const E2PArgs& a, int n, int h, int w)
+{
+    float lon, lat, x, q, t, inv, u, v;
+    e2p_lonlat(a, n, h, w, lon, lat, x, q, t, inv);
+    e2p_uv(lon, lat, u, v);
+    // ATen grid_sampler: unnormalise (align_corners) then clip (border)
+    float ix = (u + 1.0f) * a.sx_scale, iy = (v + 1.0f) * a.sy_scale;
+    ix = fminf((float)(a.W - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(a.H - 1), fmaxf(iy, 0.0f));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    Tap p;
+    p.tx = ix - fx; p.ty = iy - fy;
+    p.dx = (x0 + 1 < a.W) ? 1 : 0;
+    p.dy = (y0 + 1 < a.H) ? a.W : 0;
+    p.o00 = y0 * a.W + x0;
+    return p;
+}
+
+template <typename T>
+__device__ __forceinline__ float e2p_fetch(const T* __restrict__ img, const Tap& p)
+{
+    // out-of-range +1 taps carry exactly zero weight in ATen (they are skipped); with dx/dy = 0
+    // they alias the in-range tap and are multiplied by tx = 0 / ty = 0 — unless the image holds
+    // non-finite values, hence the explicit selects.
+    const float v00 = Store<T>::ld(img + p.o00);
+    const float v01 = p.dx ? Store<T>::ld(img + p.o00 + 1) : 0.0f;
+    const float v10 = p.dy ? Store<T>::ld(img + p.o00 + p.dy) : 0.0f;
+    const float v11 = (p.dx && p.dy) ? Store<T>::ld(img + p.o00 + p.dy + 1) : 0.0f;
+    const float ex = 1.0f - p.tx, ey = 1.0f - p.ty;
+    return v00 * (ey * ex) + v01 * (ey * p.tx) + v10 * (p.ty * ex) + v11 * (p.ty * p.tx);
+}
+
+// ------------------------------------------------------------------ planar output [B,N,C,ph,pw]
+// grid.x = N * blocks_per_patch; a thread owns VEC consecutive elements of patch n's flattened
+// (h,w) plane and streams all B*C planes through them.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void e2p_planar_kernel(E2PArgs a, int blocks_per_patch, int nblocks)
+{
+    const unsigned lb = omni_xcd_remap(blockIdx.x, nblocks);
+    const int n = lb / blocks_per_patch;
+    const int e0 = ((lb % blocks_per_patch) * 256 + threadIdx.x) * VEC;
+    const int plane = a.ph * a.pw;
+    if (e0 >= plane) return;
+    Tap tp[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int e = min(e0 + k, plane - 1);
+        tp[k] = e2p_tap(a, n, e / a.pw, e % a.pw);
+    }
+    const T* erp = (const T*)a.erp;
+    T* out = (T*)a.pers;
+    const size_t img_plane = (size_t)a.H * a.W;
+    for (int b = 0; b < a.B; ++b) {
+        for (int c = 0; c < a.C; ++c) {
+            const T* img = erp + ((size_t)b * a.C + c) * img_plane;
+            T* dst = out + (((size_t)b * a.tab.N + n) * a.C + c) * plane + e0;
+            float r[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) r[k] = e2p_fetch(img, tp[k]);
+            if (VEC == 4 && e0 + 3 < plane) {
+                if (sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+                } else {
+                    __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]);
+                    uint2 pk; pk.x = *reinterpret_cast<unsigned*>(&lo); pk.y = *reinterpret_cast<unsigned*>(&hi);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) if (e0 + k < plane) Store<T>::st(dst + k, r[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ reference output [B,C,ph,pw,N]
+// A block owns one patch row h and TW = 64 columns for ALL N patches.  Wave v gathers patches
+// v, v+4, ... with lane <-> w (good ERP locality), parks the results in an LDS tile laid out
+// exactly like the destination ([w][n], N innermost), and the whole block then streams the tile
+// out as one contiguous run of TW*N elements: the unfold/reshape of equi2pers_v3.py:112-113
+// costs no extra HBM pass and the N-innermost stores stay coalesced.
+constexpr int E2P_TW = 64;
+constexpr int E2P_CCH = 4;                       // image planes staged per LDS round
+constexpr int E2P_MAXPW = (OMNI_MAX_PATCH + 3) / 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void e2p_reflayout_kernel(E2PArgs a, int tiles_w)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* tile = reinterpret_cast<float*>(smem_raw);          // [E2P_CCH][TW*N]
+    const int N = a.tab.N;
+    const int h = blockIdx.x / tiles_w;
+    const int w0 = (blockIdx.x % tiles_w) * E2P_TW;
+    const int wv = min(E2P_TW, a.pw - w0);                     // valid columns in this tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int run = wv * N;                                    // contiguous elements per plane
+    const int npw = (N + 3) >> 2;
+
+    Tap tp[E2P_MAXPW];
+#pragma unroll
+    for (int k = 0; k < E2P_MAXPW; ++k) {
+        const int n = wave + 4 * k;
+        if (k < npw && n < N) tp[k] = e2p_tap(a, n, h, min(w0 + lane, a.pw - 1));
+    }
+    const T* erp = (const T*)a.erp;
+    T* out = (T*)a.pers;
+    const size_t img_plane = (size_t)a.H * a.W;
+    const size_t out_plane = (size_t)a.ph * a.pw * N;
+    const size_t out_off = ((size_t)h * a.pw + w0) * N;
+    const int planes = a.B * a.C;
+    for (int p0 = 0; p0 < planes; p0 += E2P_CCH) {
+        const int pc = min(E2P_CCH, planes - p0);
+        for (int pp = 0; pp < pc; ++pp) {
+            const T* img = erp + (size_t)(p0 + pp) * img_plane;
+#pragma unroll
+            for (int k = 0; k < E2P_MAXPW; ++k) {
+                const int n = wave + 4 * k;
+                if (k < npw && n < N && lane < wv)
+                    tile[pp * (E2P_TW * N) + lane * N + n] = e2p_fetch(img, tp[k]);
+            }
+        }
+        __syncthreads();
+        for (int pp = 0; pp < pc; ++pp) {
+            T* dst = out + (size_t)(p0 + pp) * out_plane + out_off;
+            const float* src = tile + pp * (E2P_TW * N);
+            for (int i = threadIdx.x; i < run; i += 256) Store<T>::st(dst + i, src[i]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ aux outputs
+// xyz[n,:,h,w] = (cos lat sin lon, cos lat cos lon, sin lat) from the UNWRAPPED lon (:13-18,115-118),
+// here without further trig:  cos lat * (sin|cos)(l0 + atan2(x,q)) = inv * (..) algebraically.
+// uv[b,:,h,a] = strip[h, a*N + b]  (:106-108,120 — the reference reinterprets the [ph, N*pw] strip
+// as [ph, pw, N]).
+__global__ __launch_bounds__(256) void e2p_aux_kernel(E2PArgs a, float* xyz, float* uv)
+{
+    const int N = a.tab.N, plane = a.ph * a.pw;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * plane) return;
+    const int n = idx / plane, e = idx % plane, h = e / a.pw, w = e % a.pw;
+    if (xyz) {
+        float lon, lat, x, q, t, inv;
+        e2p_lonlat(a, n, h, w, lon, lat, x, q, t, inv);
+        const float sl = a.tab.slam[n], cl = a.tab.clam[n];
+        xyz[((size_t)n * 3 + 0) * plane + e] = inv * (sl * q + cl * x);
+        xyz[((size_t)n * 3 + 1) * plane + e] = inv * (cl * q - sl * x);
+        xyz[((size_t)n * 3 + 2) * plane + e] = fminf(1.0f, fmaxf(-1.0f, t * inv));
+    }
+    if (uv) {
+        const int s = w * N + n;                     // here (n, w) play the roles (b, a)
+        const int n2 = s / a.pw, w2 = s % a.pw;
+        float lon, lat, x, q, t, inv, u, v;
+        e2p_lonlat(a, n2, h, w2, lon, lat, x, q, t, inv);
+        e2p_uv(lon, lat, u, v);
+        uv[((size_t)n * 2 + 0) * plane + e] = u;
+        uv[((size_t)n * 2 + 1) * plane + e] = v;
+    }
+}
+
+void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, int B, int C)
+{
+    a.erp = erp; a.pers = pers; a.B = B; a.C = C; a.H = g->H; a.W = g->W; a.ph = g->ph; a.pw = g->pw;
+    a.fovx = g->fov_w / 360.0f; a.fovy = g->fov_h / 180.0f;
+    a.stepx = g->pw > 1 ? 1.0f / (float)(g->pw - 1) : 0.0f;
+    a.stepy = g->ph > 1 ? 1.0f / (float)(g->ph - 1) : 0.0f;
+    a.sx_scale = (float)(g->W - 1) / 2.0f; a.sy_scale = (float)(g->H - 1) / 2.0f;
+    a.tab = g->e2p;
+}
+
+template <typename T>
+int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C, int layout, hipStream_t stream)
+{
+    E2PArgs a; fill_args(a, g, erp, pers, B, C);
+    const int plane = g->ph * g->pw, N = g->N;
+    if (layout == OMNI_LAYOUT_BNCHW) {
+        const bool vec = (plane % 4) == 0;
+        const int per_block = 256 * (vec ? 4 : 1);
+        const int bpp = (plane + per_block - 1) / per_block;
+        const int nblocks = N * bpp;
+        if (vec) hipLaunchKernelGGL((e2p_planar_kernel<T, 4>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
+        else     hipLaunchKernelGGL((e2p_planar_kernel<T, 1>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
+    } else if (layout == OMNI_LAYOUT_BCHWN) {
+        const int tiles_w = (g->pw + E2P_TW - 1) / E2P_TW;
+        const size_t lds = sizeof(float) * E2P_CCH * E2P_TW * N;
+        hipLaunchKernelGGL((e2p_reflayout_kernel<T>), dim3(g->ph * tiles_w), dim3(256), lds, stream, a, tiles_w);
+    } else {
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: layout must be OMNI_LAYOUT_BCHWN or OMNI_LAYOUT_BNCHW");
+    }
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+}  // namespace
+
+extern "C" int omni_equi2pers_g(const omni_geometry_t* g, const void* erp, void* pers, int dtype,
+                                int B, int C, int layout, omni_stream_t stream)
+{
+    if (!g) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: null geometry");
+    if (B < 0 || C < 0) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: negative batch/channels");
+    if (B == 0 || C == 0) return OMNI_OK;                         // empty input: nothing to do
+    if (g->H < 1 || g->W < 1) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: empty ERP image");
+    if (!erp || !pers) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: null device pointer");
+    if ((size_t)g->H * g->W >= (1u << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: ERP plane too large");
+    if (dtype == OMNI_F32) return launch_e2p<float>(g, erp, pers, B, C, layout, (hipStream_t)stream);
+    if (dtype == OMNI_F16) return launch_e2p<__half>(g, erp, pers, B, C, layout, (hipStream_t)stream);
+    OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: dtype must be OMNI_F32 or OMNI_F16");
+}
+
+extern "C" int omni_equi2pers(const void* erp, void* pers, int dtype, int B, int C, int H, int W,
+                              int ph, int pw, int nrows, float fov_h, float fov_w, int layout,
+                              omni_stream_t stream)
+{
+    const omni_geometry* g = nullptr;
+    // the sampler does not need the ERP-side tables; key them by (H,W) anyway so one handle serves both operators
+    int rc = omni_geometry_lookup(&g, nrows, fov_h, fov_w, ph, pw, H, W, (hipStream_t)stream);
+    if (rc != OMNI_OK) return rc;
+    return omni_equi2pers_g(g, erp, pers, dtype, B, C, layout, stream);
+}
+
+extern "C" int omni_equi2pers_aux(float* xyz, float* uv, int ph, int pw, int nrows, float fov_h, float fov_w,
+                                  omni_stream_t stream)
+{
+    const omni_geometry* g = nullptr;
+    int rc = omni_geometry_lookup(&g, nrows, fov_h, fov_w, ph, pw, 0, 0, (hipStream_t)stream);
+    if (rc != OMNI_OK) return rc;
+    if (!xyz && !uv) return OMNI_OK;
+    E2PArgs a; fill_args(a, g, nullptr, nullptr, 0, 0);
+    const int total = g->N * ph * pw;
+    hipLaunchKernelGGL(e2p_aux_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, xyz, uv);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

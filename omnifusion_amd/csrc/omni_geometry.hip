@@ -1,0 +1,169 @@
+// omni_geometry.hip — patch presets, geometry handles and the per-device handle cache.
+//
+// Replaces the per-call CPU work of the reference: the patch-centre tables
+// (equi2pers_v3.py:32-47,52-84; pers2equi_v3.py:36-74), the ERP lat/lon grid
+// (pers2equi_v3.py:109-111) and the ./grid/<layer_name>.pth cache (:24-29,155-167).
+// Everything here is a constant of (nrows, fov, patch size, ERP size): a few KB that
+// stay resident on the device.
+#include <math.h>
+#include <mutex>
+#include <vector>
+#include <memory>
+
+#include "omni_internal.h"
+
+static thread_local std::string g_err;
+void omni_set_error(const std::string& msg) { g_err = msg; }
+extern "C" const char* omni_last_error(void) { return g_err.c_str(); }
+extern "C" int omni_version(void) { return OMNI_VERSION; }
+
+// ---------------------------------------------------------------- presets
+namespace {
+struct Preset { int nr; const int* cols; const double* phis; };
+
+bool preset(int nrows, int which, Preset& p)
+{
+    static const int c4[] = {3, 6, 6, 3};            static const double p4[] = {-67.5, -22.5, 22.5, 67.5};
+    static const int c6[] = {3, 8, 12, 12, 8, 3};    static const double p6[] = {-75.2, -45.93, -15.72, 15.72, 45.93, 75.2};
+    static const int c3[] = {3, 4, 3};               static const double p3e[] = {-60, 0, 60};
+    static const double p3p[] = {-59.6, 0, 59.6};    // pers2equi_v3.py:47 (differs from equi2pers)
+    static const int c5[] = {3, 6, 8, 6, 3};         static const double p5[] = {-72.2, -36.1, 0, 36.1, 72.2};
+    switch (nrows) {
+    case 4: p = {4, c4, p4}; return true;
+    case 6: p = {6, c6, p6}; return true;
+    case 3: p = {3, c3, which ? p3p : p3e}; return true;
+    case 5: p = {5, c5, p5}; return true;
+    default: return false;
+    }
+}
+
+// fp32 centre angles exactly as the reference rounds them (equi2pers_v3.py:77-84).
+int centers(int nrows, int which, float* lam0, float* phi1, float* center_p)
+{
+    Preset p;
+    if (!preset(nrows, which, p)) return -1;
+    const float PI_F = (float)M_PI, PI_2_F = (float)(M_PI * 0.5);
+    int n = 0;
+    for (int i = 0; i < p.nr; ++i)
+        for (int j = 0; j < p.cols[i]; ++j) {
+            double ti = 360.0 / p.cols[i];
+            double tc = j * ti + ti / 2;
+            float cx = (float)tc / 360.0f;
+            float cy = ((float)p.phis[i] + 90.0f) / 180.0f;
+            float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
+            if (center_p) { center_p[2 * n] = px; center_p[2 * n + 1] = py; }
+            if (lam0) lam0[n] = px * PI_F;
+            if (phi1) phi1[n] = py * PI_2_F;
+            ++n;
+        }
+    return n;
+}
+
+void fill_tab(PatchTab& t, int nrows, int which)
+{
+    float lam[OMNI_MAX_PATCH], phi[OMNI_MAX_PATCH];
+    t.N = centers(nrows, which, lam, phi, nullptr);
+    for (int n = 0; n < t.N; ++n) {
+        t.lam0[n] = lam[n];
+        t.slam[n] = (float)sin((double)lam[n]); t.clam[n] = (float)cos((double)lam[n]);
+        t.sphi[n] = (float)sin((double)phi[n]); t.cphi[n] = (float)cos((double)phi[n]);
+    }
+}
+
+// torch.linspace fp32 semantics (two-sided evaluation), pers2equi_v3.py:109.
+float linspace_f(float start, float end, int steps, int idx)
+{
+    if (steps == 1) return start;
+    float step = (end - start) / (float)(steps - 1);
+    int half = steps / 2;
+    return idx < half ? start + step * (float)idx : end - step * (float)(steps - idx - 1);
+}
+}  // namespace
+
+extern "C" int omni_num_patches(int nrows) { return centers(nrows, 0, nullptr, nullptr, nullptr); }
+
+extern "C" int omni_patch_centers(int nrows, int which, float* center_p_host)
+{
+    if (!center_p_host) OMNI_FAIL(OMNI_ERR_INVALID, "omni_patch_centers: null output");
+    int n = centers(nrows, which, nullptr, nullptr, center_p_host);
+    if (n < 0) OMNI_FAIL(OMNI_ERR_INVALID, "unsupported nrows " + std::to_string(nrows) + " (presets: 3,4,5,6)");
+    return OMNI_OK;
+}
+
+// ---------------------------------------------------------------- handles
+extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_h, float fov_w,
+                                    int ph, int pw, int H, int W, omni_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) OMNI_FAIL(OMNI_ERR_INVALID, "omni_geometry_create: null out");
+    if (omni_num_patches(nrows) < 0)
+        OMNI_FAIL(OMNI_ERR_INVALID, "unsupported nrows " + std::to_string(nrows) + " (presets: 3,4,5,6)");
+    if (ph < 1 || pw < 1 || H < 0 || W < 0 || ph > 32768 || pw > 32768 || H > 32768 || W > 32768)
+        OMNI_FAIL(OMNI_ERR_INVALID, "omni_geometry_create: bad patch/ERP size");
+    if (!(fov_h > 0.f) || !(fov_w > 0.f)) OMNI_FAIL(OMNI_ERR_INVALID, "omni_geometry_create: fov must be > 0");
+
+    std::unique_ptr<omni_geometry> g(new omni_geometry());
+    OMNI_HIP(hipGetDevice(&g->device));
+    g->nrows = nrows; g->fov_h = fov_h; g->fov_w = fov_w; g->ph = ph; g->pw = pw; g->H = H; g->W = W;
+    fill_tab(g->e2p, nrows, 0);
+    fill_tab(g->p2e, nrows, 1);
+    g->N = g->e2p.N;
+    centers(nrows, 0, nullptr, nullptr, g->center_p);
+    g->row_trig = nullptr; g->col_trig = nullptr; g->cand = nullptr; g->ntx = (W + 63) / 64;
+
+    if (H > 0 && W > 0) {
+        const float PI_F = (float)M_PI, PI_2_F = (float)(M_PI * 0.5);
+        std::vector<float2> rt(H), ct(W);
+        for (int i = 0; i < H; ++i) { double a = (double)linspace_f(-PI_2_F, PI_2_F, H, i); rt[i] = make_float2((float)sin(a), (float)cos(a)); }
+        for (int j = 0; j < W; ++j) { double a = (double)linspace_f(-PI_F, PI_F, W, j);     ct[j] = make_float2((float)sin(a), (float)cos(a)); }
+        OMNI_HIP(hipMalloc((void**)&g->row_trig, sizeof(float2) * H));
+        OMNI_HIP(hipMalloc((void**)&g->col_trig, sizeof(float2) * W));
+        OMNI_HIP(hipMalloc((void**)&g->cand, sizeof(unsigned long long) * (size_t)H * g->ntx));
+        // synchronous copies: the staging vectors die at scope exit (one-time setup, never on the hot path)
+        OMNI_HIP(hipMemcpy(g->row_trig, rt.data(), sizeof(float2) * H, hipMemcpyHostToDevice));
+        OMNI_HIP(hipMemcpy(g->col_trig, ct.data(), sizeof(float2) * W, hipMemcpyHostToDevice));
+        int rc = omni_p2e_build_candidates(g.get(), stream);
+        if (rc != OMNI_OK) { omni_geometry_destroy(g.release()); return rc; }
+    }
+    *out = g.release();
+    return OMNI_OK;
+}
+
+extern "C" void omni_geometry_destroy(omni_geometry_t* g)
+{
+    if (!g) return;
+    if (g->row_trig) (void)hipFree(g->row_trig);
+    if (g->col_trig) (void)hipFree(g->col_trig);
+    if (g->cand) (void)hipFree(g->cand);
+    delete g;
+}
+
+// ---------------------------------------------------------------- cache
+namespace {
+std::mutex g_mu;
+std::vector<omni_geometry*> g_cache;
+}
+
+int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, float fov_w,
+                         int ph, int pw, int H, int W, hipStream_t stream)
+{
+    int dev = 0;
+    OMNI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);      // replica threads (nn.DataParallel) may race here
+    for (omni_geometry* g : g_cache)
+        if (g->device == dev && g->nrows == nrows && g->fov_h == fov_h && g->fov_w == fov_w &&
+            g->ph == ph && g->pw == pw && g->H == H && g->W == W) { *out = g; return OMNI_OK; }
+    omni_geometry* g = nullptr;
+    int rc = omni_geometry_create(&g, nrows, fov_h, fov_w, ph, pw, H, W, stream);
+    if (rc != OMNI_OK) return rc;
+    g_cache.push_back(g);
+    *out = g;
+    return OMNI_OK;
+}
+
+extern "C" void omni_geometry_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (omni_geometry* g : g_cache) omni_geometry_destroy(g);
+    g_cache.clear();
+}

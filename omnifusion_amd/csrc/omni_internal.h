@@ -1,0 +1,74 @@
+// omni_internal.h — shared host/device declarations of libomnifusion_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/omnifusion.h"
+
+#define OMNI_MAX_PATCH 46          // nrows=6 preset
+#define OMNI_WAVE 64
+
+// ---------------------------------------------------------------- error plumbing
+void omni_set_error(const std::string& msg);
+#define OMNI_FAIL(code, msg) do { omni_set_error(msg); return (code); } while (0)
+#define OMNI_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                   \
+        omni_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return OMNI_ERR_HIP; } } while (0)
+
+// ---------------------------------------------------------------- geometry constants
+// Per-patch constants, passed to kernels BY VALUE (kernarg segment -> scalar loads,
+// the patch index is wave-uniform everywhere).  Trig of the fp32 centre angles is
+// evaluated on the host in double and rounded once.
+struct PatchTab {
+    int   N;
+    float lam0[OMNI_MAX_PATCH];    // fp32 centre longitude  (equi2pers_v3.py:83)
+    float slam[OMNI_MAX_PATCH];
+    float clam[OMNI_MAX_PATCH];
+    float sphi[OMNI_MAX_PATCH];    // sin / cos of the fp32 centre latitude (:84)
+    float cphi[OMNI_MAX_PATCH];
+};
+
+struct omni_geometry {
+    int device;
+    int nrows, N;
+    float fov_h, fov_w;
+    int ph, pw, H, W;
+    PatchTab e2p;                  // equi2pers centre table
+    PatchTab p2e;                  // pers2equi centre table (differs for nrows=3)
+    float center_p[2 * OMNI_MAX_PATCH];
+    // device-resident tables (a few KB)
+    float2* row_trig;              // [H]  (sin lat_i, cos lat_i)   pers2equi_v3.py:109
+    float2* col_trig;              // [W]  (sin lon_j, cos lon_j)
+    unsigned long long* cand;      // [H][ntx] bit n set <=> patch n covers >=1 pixel of the 64-px tile
+    int ntx;
+};
+
+// implemented in omni_geometry.hip
+int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, float fov_w,
+                         int ph, int pw, int H, int W, hipStream_t stream);
+// implemented in omni_pers2equi.hip: fills g->cand on `stream`
+int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream);
+
+// ---------------------------------------------------------------- storage types
+template <typename T> struct Store;
+template <> struct Store<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Store<__half> {
+    static __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
+    static __device__ __forceinline__ void st(__half* p, float v) { *p = __float2half_rn(v); }
+};
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"); give every XCD one CONTIGUOUS range of logical tiles so that
+// neighbouring tiles (which share gather footprints) share one L2.  Pure speed: results
+// never depend on placement.
+__device__ __forceinline__ unsigned omni_xcd_remap(unsigned bid, unsigned nblocks)
+{
+    const unsigned per = nblocks >> 3;                 // tiles per XCD (full part)
+    const unsigned full = per << 3;
+    if (bid >= full) return bid;                       // ragged tail keeps identity
+    return (bid & 7u) * per + (bid >> 3);
+}

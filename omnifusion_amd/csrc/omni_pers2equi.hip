@@ -1,0 +1,274 @@
+// omni_pers2equi.hip — N tangent-plane patches -> one ERP map (gfx950).
+//
+// Replaces /root/reference/equi_pers/pers2equi_v3.py:16-198:
+//   K6  [N,H,W] int64 tap tables + [N,H,W,4] weights, torch.save / torch.load of a 0.5 GB file
+//       per call (:29-167)                          -> evaluated in-kernel per (pixel, patch)
+//   K7  4 dense advanced-index gathers [B,C,N,H,W] (:174-177) -> gathers over COVERING patches only
+//   K8  mask multiply, permutes (:179-187)          -> fused
+//   K9  threshold 1e-5, L1-normalise over N*4 (:189-193) -> running sum of weights
+//   K10 weighted sum (:194-196)                     -> fused
+//   K11 confidence fusion, spherical_model.py:307-311 -> p2e kernel with CONF = true
+//
+// One thread owns one ERP pixel and all B*C planes of it; a wave owns 64 consecutive pixels
+// of one ERP row.  Which patches can cover a 64-pixel tile is a constant of the geometry: a
+// 64-bit mask per tile (H * ceil(W/64) words, built once by p2e_candidates_kernel with the SAME
+// device function the blend uses, so the mask is an exact superset by construction).  The blend
+// loops over the set bits only (wave-uniform scalar loop; mean 2.1 of 18 patches for nrows=4,
+// 4.8 of 46 for nrows=6) instead of the reference's dense N.
+//
+// Per (pixel, patch) arithmetic follows pers2equi_v3.py:112-152 exactly in structure —
+// including the quirks that define parity (X scaled by height and compared with
+// width, clamped x1/y1 in the weights, strict 0<X<P mask, threshold 1e-5, L1 over all taps) —
+// but takes sin/cos of lat_i, lon_j and the centre angles from tables evaluated in double on the
+// host:  cos(lon-l0) = cos lon cos l0 + sin lon sin l0  etc.  No transcendental in the kernel.
+//
+// HBM-bound: algorithmic bytes B*C*(ph*pw*N + H*W)*sizeof(T); tables read: 8 B per tile.
+#include "omni_internal.h"
+
+namespace {
+
+struct P2EArgs {
+    const void* pers; const void* pers2;      // pers2: confidence tensor for the fused K11 blend
+    void* erp;
+    const float2* row_trig; const float2* col_trig;
+    const unsigned long long* cand;
+    int B, C, H, W, ph, pw, ntx;
+    long long sB, sC, sN, sY, sX;              // element strides of the patch tensor
+    float kx, ky;                              // 1/(FOVx*PI), 1/(FOVy*PI_2)   (:115-116)
+    float half_h, half_w;                      // 0.5*height, 0.5*width        (:122-123)
+    PatchTab tab;
+};
+
+struct Taps { int x0, x1, y0, y1; float wa, wb, wc, wd; };
+
+
+// pers2equi_v3.py:112-152 + :191 for one (pixel, patch).  Returns the validity mask.
+__device__ __forceinline__ bool p2e_taps(const P2EArgs& a, int n, float slat, float clat, float slon, float clon, Taps& t)
+{
+    const float sl0 = a.tab.slam[n], cl0 = a.tab.clam[n], sp = a.tab.sphi[n], cp = a.tab.cphi[n];
+    const float cd = clon * cl0 + slon * sl0;                       // cos(lon - l0)
+    const float sd = slon * cl0 - clon * sl0;                       // sin(lon - l0)
+    const float cos_c = sp * slat + cp * clat * cd;                 // :112
+    float nx = (clat * sd) / cos_c;                                 // :113
+    float ny = (cp * slat - sp * clat * cd) / cos_c;                // :114
+    nx = nx * a.kx;                                                 // :115
+    ny = ny * a.ky;                                                 // :116
+    const float X = (nx + 1.0f) * a.half_h;                         // :122 (sic)
+    const float Y = (ny + 1.0f) * a.half_w;                         // :123 (sic)
+    const float fw = (float)a.pw, fh = (float)a.ph;
+    const bool valid = (X < fw) && (X > 0.0f) && (Y < fh) && (Y > 0.0f) && (cos_c > 0.0f);   // :118,126-127
+    const float fx = floorf(X), fy = floorf(Y);                     // :129-132
+    const float x0f = fminf(fmaxf(fx, 0.0f), fw - 1.0f), x1f = fminf(fmaxf(fx + 1.0f, 0.0f), fw - 1.0f);   // :134-137
+    const float y0f = fminf(fmaxf(fy, 0.0f), fh - 1.0f), y1f = fminf(fmaxf(fy + 1.0f, 0.0f), fh - 1.0f);
+    float wa = (x1f - X) * (y1f - Y);                               // :139  tap (y0,x0)
+    float wb = (x1f - X) * (Y - y0f);                               // :140  tap (y1,x0)
+    float wc = (X - x0f) * (y1f - Y);                               // :141  tap (y0,x1)
+    float wd = (X - x0f) * (Y - y0f);                               // :142  tap (y1,x1)
+    // :144-147 multiply by mask, :191 zero everything <= 1e-5
+    t.wa = (valid && wa > 1e-5f) ? wa : 0.0f;
+    t.wb = (valid && wb > 1e-5f) ? wb : 0.0f;
+    t.wc = (valid && wc > 1e-5f) ? wc : 0.0f;
+    t.wd = (valid && wd > 1e-5f) ? wd : 0.0f;
+    t.x0 = (int)x0f; t.x1 = (int)x1f; t.y0 = (int)y0f; t.y1 = (int)y1f;
+    return valid;
+}
+
+// One wave per 64-pixel tile: bit n of cand[row][tile] = any lane valid for patch n.
+__global__ __launch_bounds__(256) void p2e_candidates_kernel(P2EArgs a, unsigned long long* cand)
+{
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= a.H * a.ntx) return;
+    const int i = wave / a.ntx, j = (wave % a.ntx) * 64 + lane;
+    const float2 rt = a.row_trig[i];
+    const float2 ct = a.col_trig[min(j, a.W - 1)];
+    unsigned long long m = 0;
+    for (int n = 0; n < a.tab.N; ++n) {
+        Taps t;
+        const bool v = p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t) && (j < a.W);
+        if (__ballot(v) != 0ull) m |= (1ull << n);
+    }
+    if (lane == 0) cand[wave] = m;
+}
+
+// Blend.  PL = planes accumulated per pass (B*C are walked in chunks of PL).
+template <typename T, int PL, bool CONF>
+__global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4, int nblocks)
+{
+    // block = 4 waves = 4 consecutive rows x 64 columns (vertical neighbours share gather lines in L1)
+    const unsigned lb = omni_xcd_remap(blockIdx.x, nblocks);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = lb % a.ntx;
+    const int i = __builtin_amdgcn_readfirstlane((int)(lb / a.ntx) * 4 + wave);   // wave-uniform row
+    const int j = tx * 64 + lane;
+    if (i >= a.H) return;
+    const bool inside = j < a.W;
+    const float2 rt = a.row_trig[i];
+    const float2 ct = a.col_trig[inside ? j : a.W - 1];
+    const unsigned long long cm_ = a.cand[(size_t)i * a.ntx + tx];
+    // keep the candidate mask in SGPRs: the patch loop below is then a scalar loop and the
+    // per-patch constants come in through scalar loads from the kernarg segment
+    const unsigned long long cmask = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cm_ >> 32)) << 32)
+                                   | (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)cm_);
+    const T* pers = (const T*)a.pers;
+    const T* pers2 = (const T*)a.pers2;
+    const int planes = CONF ? a.B : a.B * a.C;
+    const size_t erp_plane = (size_t)a.H * a.W;
+    const size_t pix = (size_t)i * a.W + j;
+
+    for (int p0 = 0; p0 < planes; p0 += PL) {
+        float acc[PL], acc2[CONF ? PL : 1];
+#pragma unroll
+        for (int k = 0; k < PL; ++k) acc[k] = 0.0f;
+        if (CONF) {
+#pragma unroll
+            for (int k = 0; k < PL; ++k) acc2[k] = 0.0f;
+        }
+        float l1 = 0.0f;
+        unsigned long long m = cmask;
+        while (m) {                                            // wave-uniform loop over candidate patches
+            const int n = __builtin_ctzll(m);
+            m &= m - 1;
+            Taps t;
+            p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+            l1 += (t.wa + t.wb) + (t.wc + t.wd);               // all >= 0 after the threshold
+            const bool any = (t.wa + t.wb + t.wc + t.wd) > 0.0f;
+            if (!__any(any && inside)) continue;
+            const long long oa = (long long)t.y0 * a.sY + (long long)t.x0 * a.sX + (long long)n * a.sN;
+            const long long ob = (long long)t.y1 * a.sY + (long long)t.x0 * a.sX + (long long)n * a.sN;
+            const long long oc = (long long)t.y0 * a.sY + (long long)t.x1 * a.sX + (long long)n * a.sN;
+            const long long od = (long long)t.y1 * a.sY + (long long)t.x1 * a.sX + (long long)n * a.sN;
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < PL; ++k) {
+                    const int p = p0 + k;
+                    if (p < planes) {
+                        const long long base = CONF ? (long long)p * a.sB
+                                                    : (long long)(p / a.C) * a.sB + (long long)(p % a.C) * a.sC;
+                        const T* q = pers + base;
+                        acc[k] += Store<T>::ld(q + oa) * t.wa + Store<T>::ld(q + ob) * t.wb
+                                + Store<T>::ld(q + oc) * t.wc + Store<T>::ld(q + od) * t.wd;
+                        if (CONF) {
+                            const T* q2 = pers2 + base;
+                            acc2[k] += Store<T>::ld(q2 + oa) * t.wa + Store<T>::ld(q2 + ob) * t.wb
+                                     + Store<T>::ld(q2 + oc) * t.wc + Store<T>::ld(q2 + od) * t.wd;
+                        }
+                    }
+                }
+            }
+        }
+        if (inside) {
+            const float rden = 1.0f / fmaxf(l1, 1e-12f);           // F.normalize(p=1, eps=1e-12), :192
+#pragma unroll
+            for (int k = 0; k < PL; ++k) {
+                const int p = p0 + k;
+                if (p < planes) {
+                    if (CONF) {
+                        const float pr = acc[k] * rden, cf = acc2[k] * rden;
+                        const float z = (cf <= 1e-8f) ? 1.0f : 0.0f;                // spherical_model.py:310
+                        reinterpret_cast<float*>(a.erp)[(size_t)p * erp_plane + pix] = pr / (cf + 1e-8f * z);   // :311
+                    } else {
+                        Store<T>::st(reinterpret_cast<T*>(a.erp) + (size_t)p * erp_plane + pix, acc[k] * rden);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int fill_args(P2EArgs& a, const omni_geometry* g, const void* pers, const void* pers2, void* erp,
+              int B, int C, int layout)
+{
+    a.pers = pers; a.pers2 = pers2; a.erp = erp;
+    a.row_trig = g->row_trig; a.col_trig = g->col_trig; a.cand = g->cand;
+    a.B = B; a.C = C; a.H = g->H; a.W = g->W; a.ph = g->ph; a.pw = g->pw; a.ntx = g->ntx;
+    const long long N = g->N, ph = g->ph, pw = g->pw;
+    if (layout == OMNI_LAYOUT_BCHWN)      { a.sX = N; a.sY = pw * N; a.sN = 1; a.sC = ph * pw * N; a.sB = C * a.sC; }
+    else if (layout == OMNI_LAYOUT_BNCHW) { a.sX = 1; a.sY = pw; a.sC = ph * pw; a.sN = C * a.sC; a.sB = N * a.sN; }
+    else if (layout == OMNI_LAYOUT_BNHWC) { a.sC = 1; a.sX = C; a.sY = pw * C; a.sN = ph * a.sY; a.sB = N * a.sN; }
+    else OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi: unknown layout");
+    const float PIf = (float)M_PI, PI2f = (float)(M_PI * 0.5);
+    // the reference divides twice in fp32 (new_x / FOV[0] / PI); a reciprocal product differs by <= 1.5 ulp
+    a.kx = (float)(1.0 / ((double)(g->fov_w / 360.0f) * (double)PIf));
+    a.ky = (float)(1.0 / ((double)(g->fov_h / 180.0f) * (double)PI2f));
+    a.half_h = 0.5f * (float)g->ph; a.half_w = 0.5f * (float)g->pw;
+    a.tab = g->p2e;
+    return OMNI_OK;
+}
+
+template <typename T, bool CONF>
+int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void* erp, int B, int C,
+               int layout, hipStream_t stream)
+{
+    P2EArgs a;
+    int rc = fill_args(a, g, pers, pers2, erp, B, C, layout);
+    if (rc != OMNI_OK) return rc;
+    const int rows4 = (g->H + 3) / 4;
+    const int nblocks = rows4 * g->ntx;
+    const int planes = CONF ? B : B * C;
+    if (planes <= 1)      hipLaunchKernelGGL((p2e_kernel<T, 1, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    else if (planes <= 2) hipLaunchKernelGGL((p2e_kernel<T, 2, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    else if (planes <= 4) hipLaunchKernelGGL((p2e_kernel<T, 4, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    else                  hipLaunchKernelGGL((p2e_kernel<T, 8, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+int check_common(const omni_geometry* g, int B, int C, const char* who)
+{
+    if (!g) OMNI_FAIL(OMNI_ERR_INVALID, std::string(who) + ": null geometry");
+    if (B < 0 || C < 0) OMNI_FAIL(OMNI_ERR_INVALID, std::string(who) + ": negative batch/channels");
+    if (g->H < 1 || g->W < 1) OMNI_FAIL(OMNI_ERR_INVALID, std::string(who) + ": empty ERP size");
+    return OMNI_OK;
+}
+}  // namespace
+
+int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream)
+{
+    P2EArgs a;
+    int rc = fill_args(a, g, nullptr, nullptr, nullptr, 0, 1, OMNI_LAYOUT_BNCHW);
+    if (rc != OMNI_OK) return rc;
+    const int waves = g->H * g->ntx;
+    hipLaunchKernelGGL(p2e_candidates_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, a, g->cand);
+    OMNI_HIP(hipGetLastError());
+    // one-time setup: make the table visible to every stream that may use this handle later
+    OMNI_HIP(hipStreamSynchronize(stream));
+    return OMNI_OK;
+}
+
+extern "C" int omni_pers2equi_g(const omni_geometry_t* g, const void* pers, void* erp, int dtype, int B, int C,
+                                int layout, omni_stream_t stream)
+{
+    int rc = check_common(g, B, C, "omni_pers2equi");
+    if (rc != OMNI_OK) return rc;
+    if (B == 0 || C == 0) return OMNI_OK;
+    if (!pers || !erp) OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi: null device pointer");
+    if (dtype == OMNI_F32) return launch_p2e<float, false>(g, pers, nullptr, erp, B, C, layout, (hipStream_t)stream);
+    if (dtype == OMNI_F16) return launch_p2e<__half, false>(g, pers, nullptr, erp, B, C, layout, (hipStream_t)stream);
+    OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi: dtype must be OMNI_F32 or OMNI_F16");
+}
+
+extern "C" int omni_pers2equi(const void* pers, void* erp, int dtype, int B, int C, int ph, int pw,
+                              int H, int W, int nrows, float fov_h, float fov_w, int layout,
+                              omni_stream_t stream)
+{
+    const omni_geometry* g = nullptr;
+    int rc = omni_geometry_lookup(&g, nrows, fov_h, fov_w, ph, pw, H, W, (hipStream_t)stream);
+    if (rc != OMNI_OK) return rc;
+    return omni_pers2equi_g(g, pers, erp, dtype, B, C, layout, stream);
+}
+
+extern "C" int omni_pers2equi_conf(const void* pred_w, const void* conf, float* out, int dtype, int B,
+                                   int ph, int pw, int H, int W, int nrows, float fov_h, float fov_w,
+                                   int layout, omni_stream_t stream)
+{
+    const omni_geometry* g = nullptr;
+    int rc = omni_geometry_lookup(&g, nrows, fov_h, fov_w, ph, pw, H, W, (hipStream_t)stream);
+    if (rc != OMNI_OK) return rc;
+    rc = check_common(g, B, 1, "omni_pers2equi_conf");
+    if (rc != OMNI_OK) return rc;
+    if (B == 0) return OMNI_OK;
+    if (!pred_w || !conf || !out) OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi_conf: null device pointer");
+    if (dtype == OMNI_F32) return launch_p2e<float, true>(g, pred_w, conf, out, B, 1, layout, (hipStream_t)stream);
+    if (dtype == OMNI_F16) return launch_p2e<__half, true>(g, pred_w, conf, out, B, 1, layout, (hipStream_t)stream);
+    OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi_conf: dtype must be OMNI_F32 or OMNI_F16");
+}

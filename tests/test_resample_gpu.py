@@ -1,0 +1,239 @@
+"""GPU parity of the HIP resample operators (through the C-ABI, via the Python mirror of the
+reference interface) against (i) golden vectors produced by the reference itself and (ii) the
+C oracle at BASELINE sizes.  Tolerances:
+
+  smooth inputs           max |d| <= 1e-3                         (strict gate)
+  i.i.d. noise, equi2pers |d| <= 1e-3 for all but 2e-5 of the samples (polar lon ill-conditioning),
+                          |d| <= 2e-2 everywhere
+  pers2equi               |d| <= 1e-3 for all but 1e-5 of the pixels (a validity predicate may flip
+                          where the reference's own X,Y sit within fp32 round-off of a patch edge)
+  fp16 storage            |d| <= 4e-3 on values in [0, 8]
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import golden, rng_uniform, smooth_erp, assert_close_outliers
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers, equi2pers_patches
+    from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi, pers2equi_conf
+    from omnifusion_amd import _lib
+    return equi2pers, equi2pers_patches, pers2equi, pers2equi_conf, _lib
+
+
+def _oracle():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("name", ["G1_equi2pers_n4", "G2_equi2pers_n6", "G2b_equi2pers_n3",
+                                  "G2b_equi2pers_n5", "G2c_equi2pers_rect"])
+def test_equi2pers_golden(name):
+    equi2pers, equi2pers_patches, _, _, L = _ops()
+    g = golden(name)
+    fov = tuple(float(v) for v in g["fov"]); P = tuple(int(v) for v in g["patch"]); nrows = int(g["nrows"])
+    pers, xyz, uv, cp = equi2pers(t(g["erp"]), fov, nrows, P)
+    assert pers.shape == g["pers"].shape and pers.is_contiguous() and pers.device.type == "cuda"
+    assert cp.device.type == "cpu"
+    assert_close_outliers(pers.cpu().numpy(), g["pers"], tol=1e-3, max_tol=2e-2, frac=2e-5, what=name)
+    np.testing.assert_allclose(xyz.cpu().numpy(), g["xyz"], atol=1e-4)
+    np.testing.assert_allclose(uv.cpu().numpy(), g["uv"], atol=1e-4)
+    np.testing.assert_array_equal(cp.numpy(), g["center_p"])
+    # the planar layout used inside the model is the same data, re-laid
+    planar = equi2pers_patches(t(g["erp"]), fov, nrows, P, layout=L.LAYOUT_BNCHW)
+    assert torch.equal(planar.permute(0, 2, 3, 4, 1).contiguous(), pers)
+
+
+@pytest.mark.parametrize("name", ["G3_pers2equi_n4", "G3b_pers2equi_n3", "G3b_pers2equi_n5",
+                                  "G4_pers2equi_n6", "G4b_pers2equi_fov"])
+def test_pers2equi_golden(name):
+    _, _, pers2equi, _, L = _ops()
+    g = golden(name)
+    fov = tuple(float(v) for v in g["fov"]); P = g["pers"].shape[2]; nrows = int(g["nrows"])
+    H, W = (int(v) for v in g["erp_size"])
+    erp = pers2equi(t(g["pers"]), fov, nrows, (P, P), (H, W), "golden")
+    assert erp.shape == g["erp"].shape
+    assert_close_outliers(erp.cpu().numpy(), g["erp"], tol=2e-4, max_tol=1.0, frac=1e-4, what=name)
+    planar = t(g["pers"]).permute(0, 4, 1, 2, 3).contiguous()
+    erp2 = pers2equi(planar, fov, nrows, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
+    assert torch.equal(erp2, erp)
+    if "n3" in name:     # uncovered pixels are exactly zero
+        assert (erp.cpu().numpy()[g["erp"] == 0] == 0).all() and (g["erp"] == 0).sum() > 0
+
+
+def test_known_answers_config1_golden():
+    """BASELINE config-1 scale against the reference's own strided sub-samples (G8)."""
+    equi2pers, _, pers2equi, _, _ = _ops()
+    g = golden("G8_config1")
+    pers, xyz, uv, cp = equi2pers(t(rng_uniform(100, (1, 3, 512, 1024))), (80, 80), 4, (256, 256))
+    assert_close_outliers(pers.cpu().numpy()[:, :, ::8, ::8, :], g["pers_sub"], tol=1e-3, max_tol=2e-2, frac=5e-5)
+    np.testing.assert_allclose(xyz.cpu().numpy()[:, :, ::8, ::8], g["xyz_sub"], atol=1e-4)
+    np.testing.assert_allclose(uv.cpu().numpy()[:, :, ::8, ::8], g["uv_sub"], atol=1e-4)
+    e = pers2equi(t(rng_uniform(101, (1, 1, 256, 256, 18))), (80, 80), 4, (256, 256), (512, 1024), "x").cpu().numpy()
+    assert_close_outliers(e[:, :, ::4, ::4], g["erp_sub"], tol=2e-4, max_tol=1.0, frac=1e-4)
+    assert_close_outliers(e[:, :, [0, 1, 255, 256, 510, 511], :], g["erp_rows"], tol=2e-4, max_tol=1.0, frac=1e-3)
+    g3 = golden("G8_config3")
+    p3, _, _, _ = equi2pers(t(rng_uniform(102, (1, 1, 1024, 2048))), (80, 80), 6, (256, 256))
+    assert_close_outliers(p3.cpu().numpy()[:, :, ::8, ::8, :], g3["pers_sub"], tol=1e-3, max_tol=5e-2, frac=1e-4)
+    e3 = pers2equi(t(rng_uniform(103, (1, 1, 256, 256, 46))), (80, 80), 6, (256, 256), (1024, 2048), "x").cpu().numpy()
+    assert_close_outliers(e3[:, :, ::8, ::8], g3["erp_sub"], tol=2e-4, max_tol=1.0, frac=1e-4)
+
+
+# ------------------------------------------------------------------ oracle at BASELINE sizes
+@pytest.mark.parametrize("cfg", [(2, 3, 512, 1024, 4, 256), (1, 3, 1024, 2048, 6, 256), (1, 1, 256, 512, 5, 64),
+                                 (1, 2, 200, 333, 3, 50)])
+def test_equi2pers_vs_oracle(cfg):
+    equi2pers, equi2pers_patches, _, _, L = _ops()
+    co = _oracle()
+    B, C, H, W, nrows, P = cfg
+    x = smooth_erp(7, B, C, H, W)
+    ref, rxyz, ruv, rcp = co.equi2pers(x, (80, 80), nrows, (P, P))
+    pers, xyz, uv, cp = equi2pers(t(x), (80, 80), nrows, (P, P))
+    d = np.abs(pers.cpu().numpy() - ref).max()
+    assert d <= 1e-3, f"smooth-input gate: max |d| = {d}"
+    np.testing.assert_allclose(xyz.cpu().numpy(), rxyz, atol=1e-4)
+    np.testing.assert_allclose(uv.cpu().numpy(), ruv, atol=1e-4)
+    xn = rng_uniform(8, (B, C, H, W))
+    refn, _, _, _ = co.equi2pers(xn, (80, 80), nrows, (P, P))
+    got = equi2pers_patches(t(xn), (80, 80), nrows, (P, P))
+    assert_close_outliers(got.cpu().numpy(), refn, tol=1e-3, max_tol=5e-2, frac=5e-5, what=str(cfg))
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 512, 1024, 4, 256), (1, 2, 1024, 2048, 6, 256), (3, 3, 250, 500, 5, 64),
+                                 (1, 1, 100, 333, 3, 32), (9, 1, 64, 128, 4, 16)])
+def test_pers2equi_vs_oracle(cfg):
+    _, _, pers2equi, _, L = _ops()
+    co = _oracle()
+    B, C, H, W, nrows, P = cfg
+    N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+    x = rng_uniform(9, (B, C, P, P, N))
+    ref = co.pers2equi(x, (80, 80), nrows, (P, P), (H, W))
+    got = pers2equi(t(x), (80, 80), nrows, (P, P), (H, W), "o").cpu().numpy()
+    assert_close_outliers(got, ref, tol=2e-4, max_tol=1.0, frac=1e-5, what=str(cfg))
+    # consistent patches (what the model produces): strict 1e-3 gate
+    erp = smooth_erp(10, B, C, H, W)
+    xs, _, _, _ = co.equi2pers(erp, (80, 80), nrows, (P, P))
+    ref = co.pers2equi(xs, (80, 80), nrows, (P, P), (H, W))
+    got = pers2equi(t(xs), (80, 80), nrows, (P, P), (H, W), "o").cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-3
+
+
+def test_pers2equi_conf_vs_oracle():
+    _, _, _, pers2equi_conf, L = _ops()
+    co = _oracle()
+    d = rng_uniform(11, (2, 1, 128, 128, 18)) * 8.0
+    c = rng_uniform(12, (2, 1, 128, 128, 18))
+    ref = co.pers2equi_conf(d * c, c, (80, 80), 4, (128, 128), (512, 1024))
+    got = pers2equi_conf(t(d * c), t(c), (80, 80), 4, (128, 128), (512, 1024)).cpu().numpy()
+    assert_close_outliers(got, ref, tol=1e-3, max_tol=8.0, frac=1e-5)
+    # planar layout gives the same bits
+    pl = lambda a: t(a).permute(0, 4, 1, 2, 3).contiguous()
+    got2 = pers2equi_conf(pl(d * c), pl(c), (80, 80), 4, (128, 128), (512, 1024), layout=L.LAYOUT_BNCHW)
+    assert torch.equal(got2.cpu(), torch.from_numpy(got))
+    # nrows=3: uncovered pixels divide 0 by 1e-8 -> exactly 0 (spherical_model.py:310-311)
+    d3 = rng_uniform(13, (1, 1, 32, 32, 10)); c3 = rng_uniform(14, (1, 1, 32, 32, 10))
+    ref3 = co.pers2equi_conf(d3 * c3, c3, (80, 80), 3, (32, 32), (64, 128))
+    got3 = pers2equi_conf(t(d3 * c3), t(c3), (80, 80), 3, (32, 32), (64, 128)).cpu().numpy()
+    assert (got3[ref3 == 0] == 0).all() and (ref3 == 0).sum() > 0
+    assert_close_outliers(got3, ref3, tol=1e-3, max_tol=1.0, frac=1e-3)
+
+
+def test_fp16_storage():
+    equi2pers, equi2pers_patches, pers2equi, _, L = _ops()
+    co = _oracle()
+    x = smooth_erp(15, 1, 3, 256, 512) * 8.0
+    ref, _, _, _ = co.equi2pers(x, (80, 80), 4, (64, 64))
+    got = equi2pers_patches(t(x).half(), (80, 80), 4, (64, 64))
+    assert got.dtype == torch.float16
+    assert np.abs(got.float().cpu().numpy() - ref).max() <= 4e-3 * 2      # input rounding + output rounding
+    e_ref = co.pers2equi(ref[:, :1], (80, 80), 4, (64, 64), (256, 512))
+    e = pers2equi(t(ref[:, :1]).half(), (80, 80), 4, (64, 64), (256, 512), "h")
+    assert e.dtype == torch.float16
+    assert np.abs(e.float().cpu().numpy() - e_ref).max() <= 4e-3 * 2
+
+
+# ------------------------------------------------------------------ properties at full size
+def test_properties_full_size():
+    equi2pers, equi2pers_patches, pers2equi, _, L = _ops()
+    B, C, H, W, nrows, P, N = 4, 3, 512, 1024, 4, 256, 18
+    x = t(rng_uniform(20, (B, C, H, W)))
+    p = equi2pers_patches(x, (80, 80), nrows, (P, P))
+    # constant image -> constant patches ; linearity ; batch/channel independence
+    const = equi2pers_patches(torch.full((1, 1, H, W), 0.625, device=DEV), (80, 80), nrows, (P, P))
+    assert (const - 0.625).abs().max().item() <= 1e-6
+    p2 = equi2pers_patches(2.0 * x + 1.0, (80, 80), nrows, (P, P))
+    assert (p2 - (2.0 * p + 1.0)).abs().max().item() <= 1e-5
+    single = equi2pers_patches(x[2:3, 1:2], (80, 80), nrows, (P, P))
+    assert torch.equal(single, p[2:3, 1:2])
+    # sampled values stay inside the image range (convex bilinear weights)
+    assert p.min().item() >= 0.0 and p.max().item() <= 1.0
+    # partition of unity of the blend weights
+    pc = torch.full((2, 1, P, P, N), 3.25, device=DEV)
+    e = pers2equi(pc, (80, 80), nrows, (P, P), (H, W), "c")
+    assert (e - 3.25).abs().max().item() <= 1e-5
+    y = t(rng_uniform(21, (B, 2, P, P, N)))
+    e1 = pers2equi(y, (80, 80), nrows, (P, P), (H, W), "a")
+    assert torch.equal(pers2equi(y[1:2, 1:2].contiguous(), (80, 80), nrows, (P, P), (H, W), "a"), e1[1:2, 1:2])
+    e2 = pers2equi(3.0 * y, (80, 80), nrows, (P, P), (H, W), "a")
+    assert (e2 - 3.0 * e1).abs().max().item() <= 1e-5
+    assert e1.min().item() >= 0.0 and e1.max().item() <= 1.0 + 1e-6
+    # round trip ERP -> patches -> ERP of a smooth panorama stays close (P vs P-1 pixel-scale quirk)
+    xs = t(smooth_erp(22, 1, 1, H, W))
+    rt = pers2equi(equi2pers_patches(xs, (80, 80), nrows, (P, P)), (80, 80), nrows, (P, P), (H, W), "r")
+    assert (rt - xs).abs().max().item() < 0.02
+
+
+def test_high_res_config5_shape_fp16():
+    """BASELINE config 5 (2048x4096, nrows=6, 512^2, fp16): properties only (the reference cannot
+    run this size: ~20 GB of tables)."""
+    _, equi2pers_patches, pers2equi, _, L = _ops()
+    H, W, P, N = 2048, 4096, 512, 46
+    x = torch.full((1, 3, H, W), 0.5, device=DEV, dtype=torch.float16)
+    p = equi2pers_patches(x, (80, 80), 6, (P, P), layout=L.LAYOUT_BNCHW)
+    assert p.shape == (1, N, 3, P, P) and (p.float() - 0.5).abs().max().item() <= 1e-3
+    e = pers2equi(p[:, :, :1].contiguous(), (80, 80), 6, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
+    assert e.shape == (1, 1, H, W) and (e.float() - 0.5).abs().max().item() <= 1e-3
+
+
+# ------------------------------------------------------------------ edge cases and errors
+def test_edge_cases_and_errors():
+    equi2pers, equi2pers_patches, pers2equi, pers2equi_conf, L = _ops()
+    co = _oracle()
+    # empty batch
+    assert equi2pers_patches(torch.empty((0, 3, 64, 128), device=DEV), 80, 4, 16).shape == (0, 3, 16, 16, 18)
+    assert pers2equi(torch.empty((0, 1, 16, 16, 18), device=DEV), 80, 4, 16, (64, 128), "e").shape == (0, 1, 64, 128)
+    # odd patch width (scalar store path), ragged ERP width, many planes (B*C > 8)
+    x = rng_uniform(30, (5, 2, 37, 91))
+    ref, _, _, _ = co.equi2pers(x, (70, 95), 4, (10, 14))
+    for lay in (L.LAYOUT_BCHWN, L.LAYOUT_BNCHW):
+        got = equi2pers_patches(t(x), (70, 95), 4, (10, 14), layout=lay)
+        if lay == L.LAYOUT_BNCHW:
+            got = got.permute(0, 2, 3, 4, 1)
+        assert_close_outliers(got.cpu().numpy(), ref, tol=1e-3, max_tol=5e-2, frac=1e-3)
+    ref2, _, _, _ = co.equi2pers(x[:1], 80, 5, (9, 15))
+    got2 = equi2pers_patches(t(x[:1]), 80, 5, (9, 15), layout=L.LAYOUT_BNCHW).permute(0, 2, 3, 4, 1)
+    assert_close_outliers(got2.cpu().numpy(), ref2, tol=1e-3, max_tol=5e-2, frac=1e-3)
+    # errors: bad nrows / CPU tensor / wrong patch count / requires_grad
+    with pytest.raises(ValueError):
+        equi2pers(t(x), 80, 7, 16)
+    with pytest.raises(ValueError):
+        equi2pers(torch.zeros(1, 3, 8, 16), 80, 4, 16)
+    with pytest.raises(ValueError):
+        pers2equi(torch.zeros(1, 1, 16, 16, 17, device=DEV), 80, 4, 16, (64, 128), "bad")
+    with pytest.raises(ValueError):
+        pers2equi(torch.zeros(1, 1, 16, 16, 18, device=DEV), 80, 4, 8, (64, 128), "bad")
+    with pytest.raises(RuntimeError):
+        equi2pers(torch.zeros(1, 3, 8, 16, device=DEV, requires_grad=True), 80, 4, 16)
+    with torch.no_grad():
+        equi2pers(torch.zeros(1, 3, 8, 16, device=DEV, requires_grad=True), 80, 4, 16)

@@ -39,6 +39,11 @@ def load():
         raise OmniLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m omnifusion_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    # The library and PyTorch must share ONE HIP runtime (device pointers and streams cross the
+    # boundary).  Both name libamdhip64.so.7; importing torch first makes the dynamic loader bind
+    # our DT_NEEDED entry to the copy torch already mapped (loading /opt/rocm's copy first leaves
+    # two runtimes in the process and the second one sees no device).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     lib.omni_last_error.restype = ctypes.c_char_p
     lib.omni_version.restype = ctypes.c_int

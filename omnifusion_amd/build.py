@@ -4,6 +4,10 @@
 
 hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels to the
 GPU box with the gpurun snapshot.
+
+-ffp-contract=off: every kernel variant (layouts, dtypes, the candidate-mask builder vs the
+blend) must evaluate the shared geometry functions to the SAME bits; FMAs are written
+explicitly (fmaf) where they are wanted.
 """
 import glob
 import os
@@ -15,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libomnifusion_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def sources():

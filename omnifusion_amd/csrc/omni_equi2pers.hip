@@ -12,9 +12,8 @@
 //   lon = l0 + atan2(x sin c, rho cos p1 cos c - y sin p1 sin c)             (:95-100)
 // With sin c = rho/sqrt(1+rho^2), cos c = 1/sqrt(1+rho^2) this is identically
 //   lat = asin((sin p1 + y cos p1) / sqrt(1+x^2+y^2)),   lon = l0 + atan2(x, cos p1 - y sin p1)
-// which needs two transcendental calls instead of six, has no 0/0 at the patch centre
-// (reference quirk q4 only bites for odd patch sizes, where the reference's grid is NaN)
-// and differs from the reference's fp32 chain by coordinate round-off only (a few 1e-4 px
+// which needs two transcendental calls instead of six (the reference's 0/0 at an exact patch
+// centre, quirk q4, is reproduced explicitly in e2p_lonlat) and differs from the reference's fp32 chain by coordinate round-off only (a few 1e-4 px
 // away from the poles; tests/ carry the tolerance).
 //
 // Memory behaviour: one thread owns one (or four consecutive) sample position(s) and loops
@@ -34,10 +33,11 @@ struct E2PArgs {
     PatchTab tab;
 };
 
-struct Tap {                    // one bilinear footprint on the ERP
-    int o00;                    // y0*W + x0
-    int dx, dy;                 // 1 / W, or 0 when the +1 tap is outside (masked to weight 0 by ATen)
-    float tx, ty;               // fractional offsets
+struct Tap {                    // one bilinear footprint on the ERP, branch-free to fetch
+    int r0, r1;                 // element offsets of the two tap rows (see e2p_tap)
+    int sel;                    // PAIR: 1 when the 2-wide load was shifted left by one (x0 == W-1)
+                                // !PAIR: column step dx (0 when x0+1 is outside)
+    float w00, w01, w10, w11;   // ATen's nw, ne, sw, se weights
 };
 
 constexpr float PI_F = 3.14159265358979323846f;
@@ -46,7 +46,8 @@ constexpr float PI_2_F = 1.57079632679489661923f;
 __device__ __forceinline__ float lin01(int idx, int steps, float step)
 {
     // torch.linspace(0, 1, steps)[idx] in fp32 (two-sided), equi2pers_v3.py:29
-    return (idx < (steps >> 1)) ? step * (float)idx : 1.0f - step * (float)(steps - 1 - idx);
+    // (ATen evaluates the upper half as ONE fma: linspace(0,1,15)[7] = 0.49999997, not 0.5)
+    return (idx < (steps >> 1)) ? step * (float)idx : fmaf(-step, (float)(steps - 1 - idx), 1.0f);
 }
 
 // inverse gnomonic for sample (h, w) of patch n -> unwrapped lon, lat and the pieces xyz needs
@@ -64,6 +65,11 @@ __device__ __forceinline__ void e2p_lonlat(const E2PArgs& a, int n, int h, int w
     sl = fminf(1.0f, fmaxf(-1.0f, sl));
     lat = asinf(sl);
     lon = a.tab.lam0[n] + atan2f(x, q);
+    // Reference quirk q4: at x == y == 0 (the centre sample when BOTH patch dims are odd and their
+    // linspace midpoints are exactly 0.5) the reference divides 0/0 at :99 -> lat = NaN while
+    // lon = l0 + atan2(0, 0) = l0.  ATen then clips the NaN row coordinate to 0, so that sample reads
+    // the top ERP row, and xyz is NaN.  Reproduced, not fixed: it defines parity.
+    if (x == 0.0f && y == 0.0f) { lat = __builtin_nanf(""); t = lat; }
 }
 
 __device__ __forceinline__ void e2p_uv(float lon, float lat, float& u, float& v)
@@ -74,6 +80,11 @@ __device__ __forceinline__ void e2p_uv(float lon, float lat, float& u, float& v)
     if (u < -1.0f) u += 2.0f;                                  // :104
 }
 
+// Footprint of sample (h, w) of patch n.  ATen's grid_sampler skips taps that fall outside the
+// image; a clipped coordinate is integral there, so such a tap also has weight exactly 0.  The
+// outside tap is therefore ALIASED onto the in-range pixel of the same row/column (never onto a
+// pixel ATen would not have read), which keeps every load unconditional and in bounds.
+template <bool PAIR>
 __device__ __forceinline__ Tap e2p_tap(const E2PArgs& a, int n, int h, int w)
 {
     float lon, lat, x, q, t, inv, u, v;
@@ -85,67 +96,86 @@ __device__ __forceinline__ Tap e2p_tap(const E2PArgs& a, int n, int h, int w)
     iy = fminf((float)(a.H - 1), fmaxf(iy, 0.0f));
     const float fx = floorf(ix), fy = floorf(iy);
     const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
     Tap p;
-    p.tx = ix - fx; p.ty = iy - fy;
-    p.dx = (x0 + 1 < a.W) ? 1 : 0;
-    p.dy = (y0 + 1 < a.H) ? a.W : 0;
-    p.o00 = y0 * a.W + x0;
+    p.w00 = ey * ex; p.w01 = ey * tx; p.w10 = ty * ex; p.w11 = ty * tx;
+    const int y1 = min(y0 + 1, a.H - 1);
+    if (PAIR) {                                   // 8-byte loads of (xb, xb+1), xb = min(x0, W-2)
+        const int xb = min(x0, a.W - 2);
+        p.sel = x0 - xb;
+        p.r0 = y0 * a.W + xb; p.r1 = y1 * a.W + xb;
+    } else {
+        p.sel = (x0 + 1 < a.W) ? 1 : 0;
+        p.r0 = y0 * a.W + x0; p.r1 = y1 * a.W + x0;
+    }
     return p;
 }
 
-template <typename T>
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+    struct __attribute__((packed, aligned(4))) U { float x, y; };     // 4-byte aligned 8-byte load
+    static __device__ __forceinline__ void ld(const float* p, float& x, float& y)
+    { const U v = *reinterpret_cast<const U*>(p); x = v.x; y = v.y; }
+};
+template <> struct Pair<__half> {
+    static __device__ __forceinline__ void ld(const __half* p, float& x, float& y)
+    { unsigned u; __builtin_memcpy(&u, p, 4); const __half2 h = *reinterpret_cast<const __half2*>(&u);
+      x = __low2float(h); y = __high2float(h); }
+};
+
+template <typename T, bool PAIR>
 __device__ __forceinline__ float e2p_fetch(const T* __restrict__ img, const Tap& p)
 {
-    // out-of-range +1 taps carry exactly zero weight in ATen (they are skipped); with dx/dy = 0
-    // they alias the in-range tap and are multiplied by tx = 0 / ty = 0 — unless the image holds
-    // non-finite values, hence the explicit selects.
-    const float v00 = Store<T>::ld(img + p.o00);
-    const float v01 = p.dx ? Store<T>::ld(img + p.o00 + 1) : 0.0f;
-    const float v10 = p.dy ? Store<T>::ld(img + p.o00 + p.dy) : 0.0f;
-    const float v11 = (p.dx && p.dy) ? Store<T>::ld(img + p.o00 + p.dy + 1) : 0.0f;
-    const float ex = 1.0f - p.tx, ey = 1.0f - p.ty;
-    return v00 * (ey * ex) + v01 * (ey * p.tx) + v10 * (p.ty * ex) + v11 * (p.ty * p.tx);
+    float v00, v01, v10, v11;
+    if (PAIR) {
+        float ax, ay, bx, by;
+        Pair<T>::ld(img + p.r0, ax, ay);
+        Pair<T>::ld(img + p.r1, bx, by);
+        v00 = p.sel ? ay : ax; v01 = ay; v10 = p.sel ? by : bx; v11 = by;
+    } else {
+        v00 = Store<T>::ld(img + p.r0); v01 = Store<T>::ld(img + p.r0 + p.sel);
+        v10 = Store<T>::ld(img + p.r1); v11 = Store<T>::ld(img + p.r1 + p.sel);
+    }
+    return fmaf(v11, p.w11, fmaf(v10, p.w10, fmaf(v01, p.w01, v00 * p.w00)));
 }
 
 // ------------------------------------------------------------------ planar output [B,N,C,ph,pw]
-// grid.x = N * blocks_per_patch; a thread owns VEC consecutive elements of patch n's flattened
-// (h,w) plane and streams all B*C planes through them.
-template <typename T, int VEC>
+// A wave owns 256 consecutive elements of patch n's flattened (h,w) plane; lane l owns elements
+// l, l+64, l+128, l+192 of them, so every load instruction covers 64 CONSECUTIVE samples (a short
+// run of the ERP: 3-4 cache lines per tap row) and every store instruction writes one contiguous
+// 256-byte run.  Geometry is evaluated once per sample and amortised over all B*C image planes.
+constexpr int E2P_SPT = 4;                        // samples per thread
+
+template <typename T, bool PAIR>
 __global__ __launch_bounds__(256) void e2p_planar_kernel(E2PArgs a, int blocks_per_patch, int nblocks)
 {
     const unsigned lb = omni_xcd_remap(blockIdx.x, nblocks);
     const int n = lb / blocks_per_patch;
-    const int e0 = ((lb % blocks_per_patch) * 256 + threadIdx.x) * VEC;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e0 = ((lb % blocks_per_patch) * 4 + wave) * (64 * E2P_SPT) + lane;
     const int plane = a.ph * a.pw;
     if (e0 >= plane) return;
-    Tap tp[VEC];
+    Tap tp[E2P_SPT];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const int e = min(e0 + k, plane - 1);
-        tp[k] = e2p_tap(a, n, e / a.pw, e % a.pw);
+    for (int k = 0; k < E2P_SPT; ++k) {
+        const int e = min(e0 + 64 * k, plane - 1);
+        tp[k] = e2p_tap<PAIR>(a, n, e / a.pw, e % a.pw);
     }
     const T* erp = (const T*)a.erp;
-    T* out = (T*)a.pers;
+    T* out = (T*)a.pers + (size_t)n * a.C * plane + e0;
     const size_t img_plane = (size_t)a.H * a.W;
+    const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
     for (int b = 0; b < a.B; ++b) {
+#pragma unroll 2
         for (int c = 0; c < a.C; ++c) {
             const T* img = erp + ((size_t)b * a.C + c) * img_plane;
-            T* dst = out + (((size_t)b * a.tab.N + n) * a.C + c) * plane + e0;
-            float r[VEC];
+            T* dst = out + (size_t)b * out_bstride + (size_t)c * plane;
+            float r[E2P_SPT];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) r[k] = e2p_fetch(img, tp[k]);
-            if (VEC == 4 && e0 + 3 < plane) {
-                if (sizeof(T) == 4) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
-                } else {
-                    __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]);
-                    uint2 pk; pk.x = *reinterpret_cast<unsigned*>(&lo); pk.y = *reinterpret_cast<unsigned*>(&hi);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
-            } else {
+            for (int k = 0; k < E2P_SPT; ++k) r[k] = e2p_fetch<T, PAIR>(img, tp[k]);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) if (e0 + k < plane) Store<T>::st(dst + k, r[k]);
-            }
+            for (int k = 0; k < E2P_SPT; ++k)
+                if (e0 + 64 * k < plane) Store<T>::st(dst + 64 * k, r[k]);
         }
     }
 }
@@ -160,7 +190,7 @@ constexpr int E2P_TW = 64;
 constexpr int E2P_CCH = 4;                       // image planes staged per LDS round
 constexpr int E2P_MAXPW = (OMNI_MAX_PATCH + 3) / 4;
 
-template <typename T>
+template <typename T, bool PAIR>
 __global__ __launch_bounds__(256) void e2p_reflayout_kernel(E2PArgs a, int tiles_w)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -177,7 +207,7 @@ __global__ __launch_bounds__(256) void e2p_reflayout_kernel(E2PArgs a, int tiles
 #pragma unroll
     for (int k = 0; k < E2P_MAXPW; ++k) {
         const int n = wave + 4 * k;
-        if (k < npw && n < N) tp[k] = e2p_tap(a, n, h, min(w0 + lane, a.pw - 1));
+        if (k < npw && n < N) tp[k] = e2p_tap<PAIR>(a, n, h, min(w0 + lane, a.pw - 1));
     }
     const T* erp = (const T*)a.erp;
     T* out = (T*)a.pers;
@@ -193,7 +223,7 @@ __global__ __launch_bounds__(256) void e2p_reflayout_kernel(E2PArgs a, int tiles
             for (int k = 0; k < E2P_MAXPW; ++k) {
                 const int n = wave + 4 * k;
                 if (k < npw && n < N && lane < wv)
-                    tile[pp * (E2P_TW * N) + lane * N + n] = e2p_fetch(img, tp[k]);
+                    tile[pp * (E2P_TW * N) + lane * N + n] = e2p_fetch<T, PAIR>(img, tp[k]);
             }
         }
         __syncthreads();
@@ -221,9 +251,10 @@ __global__ __launch_bounds__(256) void e2p_aux_kernel(E2PArgs a, float* xyz, flo
         float lon, lat, x, q, t, inv;
         e2p_lonlat(a, n, h, w, lon, lat, x, q, t, inv);
         const float sl = a.tab.slam[n], cl = a.tab.clam[n];
-        xyz[((size_t)n * 3 + 0) * plane + e] = inv * (sl * q + cl * x);
-        xyz[((size_t)n * 3 + 1) * plane + e] = inv * (cl * q - sl * x);
-        xyz[((size_t)n * 3 + 2) * plane + e] = fminf(1.0f, fmaxf(-1.0f, t * inv));
+        const bool q4 = lat != lat;                  // quirk q4: NaN latitude poisons the whole ray
+        xyz[((size_t)n * 3 + 0) * plane + e] = q4 ? lat : inv * (sl * q + cl * x);
+        xyz[((size_t)n * 3 + 1) * plane + e] = q4 ? lat : inv * (cl * q - sl * x);
+        xyz[((size_t)n * 3 + 2) * plane + e] = q4 ? lat : fminf(1.0f, fmaxf(-1.0f, t * inv));
     }
     if (uv) {
         const int s = w * N + n;                     // here (n, w) play the roles (b, a)
@@ -251,17 +282,18 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
 {
     E2PArgs a; fill_args(a, g, erp, pers, B, C);
     const int plane = g->ph * g->pw, N = g->N;
+    const bool pair = g->W >= 2;
     if (layout == OMNI_LAYOUT_BNCHW) {
-        const bool vec = (plane % 4) == 0;
-        const int per_block = 256 * (vec ? 4 : 1);
+        const int per_block = 256 * E2P_SPT;
         const int bpp = (plane + per_block - 1) / per_block;
         const int nblocks = N * bpp;
-        if (vec) hipLaunchKernelGGL((e2p_planar_kernel<T, 4>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
-        else     hipLaunchKernelGGL((e2p_planar_kernel<T, 1>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
+        if (pair) hipLaunchKernelGGL((e2p_planar_kernel<T, true>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
+        else      hipLaunchKernelGGL((e2p_planar_kernel<T, false>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
     } else if (layout == OMNI_LAYOUT_BCHWN) {
         const int tiles_w = (g->pw + E2P_TW - 1) / E2P_TW;
         const size_t lds = sizeof(float) * E2P_CCH * E2P_TW * N;
-        hipLaunchKernelGGL((e2p_reflayout_kernel<T>), dim3(g->ph * tiles_w), dim3(256), lds, stream, a, tiles_w);
+        if (pair) hipLaunchKernelGGL((e2p_reflayout_kernel<T, true>), dim3(g->ph * tiles_w), dim3(256), lds, stream, a, tiles_w);
+        else      hipLaunchKernelGGL((e2p_reflayout_kernel<T, false>), dim3(g->ph * tiles_w), dim3(256), lds, stream, a, tiles_w);
     } else {
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: layout must be OMNI_LAYOUT_BCHWN or OMNI_LAYOUT_BNCHW");
     }

@@ -76,7 +76,8 @@ float linspace_f(float start, float end, int steps, int idx)
     if (steps == 1) return start;
     float step = (end - start) / (float)(steps - 1);
     int half = steps / 2;
-    return idx < half ? start + step * (float)idx : end - step * (float)(steps - idx - 1);
+    // ATen contracts both branches to a single FMA (checked bit-exact against torch.linspace)
+    return idx < half ? fmaf(step, (float)idx, start) : fmaf(-step, (float)(steps - idx - 1), end);
 }
 }  // namespace
 

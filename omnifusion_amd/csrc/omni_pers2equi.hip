@@ -90,8 +90,40 @@ __global__ __launch_bounds__(256) void p2e_candidates_kernel(P2EArgs a, unsigned
     if (lane == 0) cand[wave] = m;
 }
 
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+    struct __attribute__((packed, aligned(4))) U { float x, y; };     // 4-byte aligned 8-byte load
+    static __device__ __forceinline__ void ld(const float* p, float& x, float& y)
+    { const U v = *reinterpret_cast<const U*>(p); x = v.x; y = v.y; }
+};
+template <> struct Pair<__half> {
+    static __device__ __forceinline__ void ld(const __half* p, float& x, float& y)
+    { unsigned u; __builtin_memcpy(&u, p, 4); const __half2 h = *reinterpret_cast<const __half2*>(&u);
+      x = __low2float(h); y = __high2float(h); }
+};
+
+// four taps of one plane.  XS1: the patch rows are unit-stride in x (planar layout), so the two
+// x-taps of a row come from ONE 8-byte load of (xb, xb+1), xb = min(x0, pw-2); when x0 == pw-1 the
+// reference's clamped x1 equals x0 and both taps read element xb+1 (sel = 1).
+template <typename T, bool XS1>
+__device__ __forceinline__ float p2e_fetch(const T* __restrict__ q, unsigned o0, unsigned o1, unsigned dx, int sel,
+                                           const Taps& t)
+{
+    float va, vb, vc, vd;
+    if (XS1) {
+        float ax, ay, bx, by;
+        Pair<T>::ld(q + o0, ax, ay);
+        Pair<T>::ld(q + o1, bx, by);
+        va = sel ? ay : ax; vc = ay; vb = sel ? by : bx; vd = by;
+    } else {
+        va = Store<T>::ld(q + o0); vc = Store<T>::ld(q + o0 + dx);
+        vb = Store<T>::ld(q + o1); vd = Store<T>::ld(q + o1 + dx);
+    }
+    return fmaf(vd, t.wd, fmaf(vc, t.wc, fmaf(vb, t.wb, va * t.wa)));
+}
+
 // Blend.  PL = planes accumulated per pass (B*C are walked in chunks of PL).
-template <typename T, int PL, bool CONF>
+template <typename T, int PL, bool CONF, bool XS1>
 __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4, int nblocks)
 {
     // block = 4 waves = 4 consecutive rows x 64 columns (vertical neighbours share gather lines in L1)
@@ -107,13 +139,16 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
     const unsigned long long cm_ = a.cand[(size_t)i * a.ntx + tx];
     // keep the candidate mask in SGPRs: the patch loop below is then a scalar loop and the
     // per-patch constants come in through scalar loads from the kernarg segment
-    const unsigned long long cmask = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cm_ >> 32)) << 32)
-                                   | (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)cm_);
+    // (readfirstlane returns a signed int: go through unsigned or bit 31 sign-extends into bits 32..63)
+    const unsigned cm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ >> 32));
+    const unsigned cm_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ & 0xffffffffull));
+    const unsigned long long cmask = ((unsigned long long)cm_hi << 32) | (unsigned long long)cm_lo;
     const T* pers = (const T*)a.pers;
     const T* pers2 = (const T*)a.pers2;
     const int planes = CONF ? a.B : a.B * a.C;
     const size_t erp_plane = (size_t)a.H * a.W;
     const size_t pix = (size_t)i * a.W + j;
+    const unsigned sX = (unsigned)a.sX, sY = (unsigned)a.sY, sN = (unsigned)a.sN;   // < 2^31 (host-checked)
 
     for (int p0 = 0; p0 < planes; p0 += PL) {
         float acc[PL], acc2[CONF ? PL : 1];
@@ -130,28 +165,29 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
             m &= m - 1;
             Taps t;
             p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
-            l1 += (t.wa + t.wb) + (t.wc + t.wd);               // all >= 0 after the threshold
-            const bool any = (t.wa + t.wb + t.wc + t.wd) > 0.0f;
-            if (!__any(any && inside)) continue;
-            const long long oa = (long long)t.y0 * a.sY + (long long)t.x0 * a.sX + (long long)n * a.sN;
-            const long long ob = (long long)t.y1 * a.sY + (long long)t.x0 * a.sX + (long long)n * a.sN;
-            const long long oc = (long long)t.y0 * a.sY + (long long)t.x1 * a.sX + (long long)n * a.sN;
-            const long long od = (long long)t.y1 * a.sY + (long long)t.x1 * a.sX + (long long)n * a.sN;
+            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);  // all >= 0 after the threshold
+            l1 += wsum;
+            const bool any = inside && wsum > 0.0f;
             if (any) {
+                unsigned o0, o1, dx = 0; int sel = 0;
+                if (XS1) {
+                    const int xb = min(t.x0, a.pw - 2);
+                    sel = t.x0 - xb;
+                    o0 = (unsigned)n * sN + (unsigned)t.y0 * sY + (unsigned)xb;
+                    o1 = (unsigned)n * sN + (unsigned)t.y1 * sY + (unsigned)xb;
+                } else {
+                    o0 = (unsigned)n * sN + (unsigned)t.y0 * sY + (unsigned)t.x0 * sX;
+                    o1 = (unsigned)n * sN + (unsigned)t.y1 * sY + (unsigned)t.x0 * sX;
+                    dx = (unsigned)(t.x1 - t.x0) * sX;
+                }
 #pragma unroll
                 for (int k = 0; k < PL; ++k) {
                     const int p = p0 + k;
                     if (p < planes) {
-                        const long long base = CONF ? (long long)p * a.sB
-                                                    : (long long)(p / a.C) * a.sB + (long long)(p % a.C) * a.sC;
-                        const T* q = pers + base;
-                        acc[k] += Store<T>::ld(q + oa) * t.wa + Store<T>::ld(q + ob) * t.wb
-                                + Store<T>::ld(q + oc) * t.wc + Store<T>::ld(q + od) * t.wd;
-                        if (CONF) {
-                            const T* q2 = pers2 + base;
-                            acc2[k] += Store<T>::ld(q2 + oa) * t.wa + Store<T>::ld(q2 + ob) * t.wb
-                                     + Store<T>::ld(q2 + oc) * t.wc + Store<T>::ld(q2 + od) * t.wd;
-                        }
+                        const size_t base = CONF ? (size_t)p * (size_t)a.sB
+                                                 : (size_t)(p / a.C) * (size_t)a.sB + (size_t)(p % a.C) * (size_t)a.sC;
+                        acc[k] += p2e_fetch<T, XS1>(pers + base, o0, o1, dx, sel, t);
+                        if (CONF) acc2[k] += p2e_fetch<T, XS1>(pers2 + base, o0, o1, dx, sel, t);
                     }
                 }
             }
@@ -195,6 +231,15 @@ int fill_args(P2EArgs& a, const omni_geometry* g, const void* pers, const void* 
     return OMNI_OK;
 }
 
+template <typename T, bool CONF, bool XS1>
+void launch_p2e_pl(const P2EArgs& a, int planes, int rows4, int nblocks, hipStream_t stream)
+{
+    if (planes <= 1)      hipLaunchKernelGGL((p2e_kernel<T, 1, CONF, XS1>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    else if (planes <= 2) hipLaunchKernelGGL((p2e_kernel<T, 2, CONF, XS1>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    else if (planes <= 4) hipLaunchKernelGGL((p2e_kernel<T, 4, CONF, XS1>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    else                  hipLaunchKernelGGL((p2e_kernel<T, 8, CONF, XS1>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+}
+
 template <typename T, bool CONF>
 int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void* erp, int B, int C,
                int layout, hipStream_t stream)
@@ -202,13 +247,13 @@ int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void
     P2EArgs a;
     int rc = fill_args(a, g, pers, pers2, erp, B, C, layout);
     if (rc != OMNI_OK) return rc;
+    if ((long long)g->N * C * g->ph * g->pw >= (1ll << 31))
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_pers2equi: one batch item of the patch tensor must hold < 2^31 elements");
     const int rows4 = (g->H + 3) / 4;
     const int nblocks = rows4 * g->ntx;
     const int planes = CONF ? B : B * C;
-    if (planes <= 1)      hipLaunchKernelGGL((p2e_kernel<T, 1, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
-    else if (planes <= 2) hipLaunchKernelGGL((p2e_kernel<T, 2, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
-    else if (planes <= 4) hipLaunchKernelGGL((p2e_kernel<T, 4, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
-    else                  hipLaunchKernelGGL((p2e_kernel<T, 8, CONF>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
+    if (a.sX == 1 && g->pw >= 2) launch_p2e_pl<T, CONF, true>(a, planes, rows4, nblocks, stream);
+    else                         launch_p2e_pl<T, CONF, false>(a, planes, rows4, nblocks, stream);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

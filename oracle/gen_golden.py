@@ -12,6 +12,7 @@ Fixture index:
   G1  equi2pers  ERP 64x128  C=3 B=2 nrows=4 P=16
   G2  equi2pers  ERP 128x256 C=3 B=2 nrows=6 P=32 ;  G2b nrows 3 and 5 (ERP 64x128, P=16)
   G2c equi2pers  non-square patch (12,20), scalar fov, C=1
+  G2d equi2pers  odd patch sizes (9,9) [quirk q4: 0/0 at the centre] and (9,15)
   G3  pers2equi  [2,1,16,16,18] -> [2,1,64,128] ;  G3b nrows=3 (uncovered pixels, +-59.6 centres), nrows=5
   G4  pers2equi  nrows=6 [2,2,32,32,46] -> [2,2,128,256]
   G5  pers2equi tables x0,y0,x1,y1,mask,w_list at 32x64 / P=8 for nrows 3,4,5,6
@@ -95,21 +96,32 @@ def g_known_answers():
     p3, _, _, _ = ref_equi2pers(torch.from_numpy(erp3), (80, 80), 6, (256, 256))
     pin3 = rng_uniform(103, (1, 1, 256, 256, 46))
     e3 = ref_pers2equi(torch.from_numpy(pin3), (80, 80), 6, (256, 256), (1024, 2048))
-    save("G8_config3", pers_sub=p3.numpy()[:, :, ::8, ::8, :], erp_sub=e3.numpy()[:, :, ::8, ::8],
-         pers_sum=np.float64(p3.double().sum()), erp_sum=np.float64(e3.double().sum()))
+    # The reference emits NaN where cos_c of some patch is EXACTLY 0 in its fp32 arithmetic
+    # (X = +-inf, inf * mask(0) = NaN, pers2equi_v3.py:113,144 -> the whole pixel after :192);
+    # record where that happens at this size.
+    e3n = e3.numpy()
+    save("G8_config3", pers_sub=p3.numpy()[:, :, ::8, ::8, :], erp_sub=e3n[:, :, ::8, ::8],
+         pers_sum=np.float64(p3.double().sum()), erp_sum=np.float64(np.nansum(e3n.astype(np.float64))),
+         erp_nan_idx=np.argwhere(~np.isfinite(e3n)).astype(np.int32))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", action="store_true")
     ap.add_argument("--only-model", action="store_true")
+    ap.add_argument("--only-known", action="store_true")
     args = ap.parse_args()
+    if args.only_known:
+        g_known_answers()
+        return
     if not args.only_model:
         g_equi2pers("G1_equi2pers_n4", 1, 2, 3, 64, 128, 4, 16, (80, 80))
         g_equi2pers("G2_equi2pers_n6", 2, 2, 3, 128, 256, 6, 32, (80, 80))
         g_equi2pers("G2b_equi2pers_n3", 3, 1, 2, 64, 128, 3, 16, (80, 80))
         g_equi2pers("G2b_equi2pers_n5", 4, 1, 2, 64, 128, 5, 16, (80, 80))
         g_equi2pers("G2c_equi2pers_rect", 5, 1, 1, 48, 80, 4, (12, 20), (60, 90))
+        g_equi2pers("G2d_equi2pers_odd", 6, 1, 1, 37, 91, 4, (9, 9), (80, 80))       # quirk q4: NaN centre rays
+        g_equi2pers("G2d_equi2pers_odd2", 7, 1, 1, 37, 91, 5, (9, 15), (80, 80))    # linspace(0,1,15)[7] != 0.5
         g_pers2equi("G3_pers2equi_n4", 11, 2, 1, 16, 18, 4, 64, 128)
         g_pers2equi("G3b_pers2equi_n3", 12, 1, 1, 16, 10, 3, 64, 128)
         g_pers2equi("G3b_pers2equi_n5", 13, 1, 1, 16, 26, 5, 64, 128)

@@ -31,7 +31,7 @@ def smooth_erp(seed, B, C, H, W, k=31, passes=2):
     return x.astype(np.float32)
 
 
-def assert_close_outliers(got, want, tol=1e-3, max_tol=1e-2, frac=1e-5, what=""):
+def assert_close_outliers(got, want, tol=1e-3, max_tol=1e-2, frac=1e-5, what="", ref_nan_max=0):
     """Parity gate for i.i.d.-noise inputs: |d| <= tol for all but a
     fraction `frac` of the elements, and |d| <= max_tol everywhere.  fp32 coordinate
     round-off next to the poles / at step predicates makes a handful of samples
@@ -40,7 +40,13 @@ def assert_close_outliers(got, want, tol=1e-3, max_tol=1e-2, frac=1e-5, what="")
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     assert np.isfinite(got).all(), f"{what}: non-finite values"
-    d = np.abs(got - want)
+    # ref_nan_max: the reference (and its restatement) emit NaN for a pixel whenever cos_c of some
+    # patch is EXACTLY 0 in fp32 (X = inf, inf * mask(0) = NaN, pers2equi_v3.py:113,144,192) — an
+    # accident of round-off (4 pixels at 1024x2048/nrows=6, none at the other configs).  The HIP
+    # path treats cos_c <= 0 as "not covered" and stays finite; those pixels are excluded here.
+    nan_ref = ~np.isfinite(want)
+    assert int(nan_ref.sum()) <= ref_nan_max, f"{what}: {int(nan_ref.sum())} non-finite reference values"
+    d = np.where(nan_ref, 0.0, np.abs(got - np.where(nan_ref, 0.0, want)))
     n_bad = int((d > tol).sum())
     allowed = int(np.ceil(frac * d.size))
     assert n_bad <= allowed, f"{what}: {n_bad} of {d.size} elements differ by > {tol} (allowed {allowed}); max {d.max():.3e}"

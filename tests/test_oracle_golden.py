@@ -32,6 +32,20 @@ def test_equi2pers_golden(name):
     np.testing.assert_array_equal(cp, g["center_p"])
 
 
+@pytest.mark.parametrize("name", ["G2d_equi2pers_odd", "G2d_equi2pers_odd2"])
+def test_equi2pers_odd_patch_quirk(name):
+    """Quirk q4 (equi2pers_v3.py:99): with both patch dims odd the centre sample is 0/0 -> NaN
+    latitude (NaN rays, top ERP row sampled); (9,15) has no NaN because ATen's linspace(0,1,15)[7]
+    is 0.49999997 (one FMA), which the restatement reproduces bit-exactly."""
+    g = golden(name)
+    P = tuple(int(v) for v in g["patch"])
+    pers, xyz, uv, cp = co.equi2pers(g["erp"], (80, 80), int(g["nrows"]), P)
+    assert_close_outliers(pers, g["pers"], tol=1e-3, max_tol=2e-2, frac=1e-3, what=name)
+    np.testing.assert_array_equal(np.isnan(xyz), np.isnan(g["xyz"]))
+    np.testing.assert_allclose(np.nan_to_num(xyz), np.nan_to_num(g["xyz"]), atol=1e-4)
+    assert np.isnan(g["xyz"]).sum() == (18 * 3 if P == (9, 9) else 0)
+
+
 @pytest.mark.parametrize("name", ["G3_pers2equi_n4", "G3b_pers2equi_n3", "G3b_pers2equi_n5",
                                   "G4_pers2equi_n6", "G4b_pers2equi_fov"])
 def test_pers2equi_golden(name):
@@ -115,3 +129,17 @@ def test_partition_of_unity_and_constant_invariance():
     erp = np.full((1, 2, 64, 128), 0.625, np.float32)
     p, _, _, _ = co.equi2pers(erp, (80, 80), 4, (16, 16))
     np.testing.assert_allclose(p, 0.625, rtol=1e-6)
+
+
+def test_known_answers_config3_and_nan_quirk():
+    """BASELINE config-3 scale (1024x2048, nrows=6).  The reference emits NaN at the pixels where
+    cos_c of some patch is exactly 0 in fp32 (inf * 0, pers2equi_v3.py:113,144,192): 4 pixels at this
+    size.  The restatement reproduces the quirk at the same pixels."""
+    g = golden("G8_config3")
+    pin = rng_uniform(103, (1, 1, 256, 256, 46))
+    e = co.pers2equi(pin, (80, 80), 6, (256, 256), (1024, 2048))
+    nan_idx = np.argwhere(~np.isfinite(e))
+    np.testing.assert_array_equal(nan_idx, g["erp_nan_idx"])
+    assert abs(np.nansum(e.astype(np.float64)) - float(g["erp_sum"])) < 0.5
+    sub = e[:, :, ::8, ::8]
+    np.testing.assert_allclose(sub, g["erp_sub"], atol=2e-4)

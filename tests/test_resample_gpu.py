@@ -88,6 +88,7 @@ def test_known_answers_config1_golden():
     assert_close_outliers(p3.cpu().numpy()[:, :, ::8, ::8, :], g3["pers_sub"], tol=1e-3, max_tol=5e-2, frac=1e-4)
     e3 = pers2equi(t(rng_uniform(103, (1, 1, 256, 256, 46))), (80, 80), 6, (256, 256), (1024, 2048), "x").cpu().numpy()
     assert_close_outliers(e3[:, :, ::8, ::8], g3["erp_sub"], tol=2e-4, max_tol=1.0, frac=1e-4)
+    assert len(g3["erp_nan_idx"]) <= 8 and np.isfinite(e3).all()      # reference NaN pixels (q11) stay finite here
 
 
 # ------------------------------------------------------------------ oracle at BASELINE sizes
@@ -120,13 +121,14 @@ def test_pers2equi_vs_oracle(cfg):
     x = rng_uniform(9, (B, C, P, P, N))
     ref = co.pers2equi(x, (80, 80), nrows, (P, P), (H, W))
     got = pers2equi(t(x), (80, 80), nrows, (P, P), (H, W), "o").cpu().numpy()
-    assert_close_outliers(got, ref, tol=2e-4, max_tol=1.0, frac=1e-5, what=str(cfg))
+    assert_close_outliers(got, ref, tol=2e-4, max_tol=1.0, frac=1e-5, what=str(cfg), ref_nan_max=8 * B * C)
     # consistent patches (what the model produces): strict 1e-3 gate
     erp = smooth_erp(10, B, C, H, W)
     xs, _, _, _ = co.equi2pers(erp, (80, 80), nrows, (P, P))
     ref = co.pers2equi(xs, (80, 80), nrows, (P, P), (H, W))
     got = pers2equi(t(xs), (80, 80), nrows, (P, P), (H, W), "o").cpu().numpy()
-    assert np.abs(got - ref).max() <= 1e-3
+    assert np.isfinite(got).all()
+    assert np.nanmax(np.abs(got - ref)) <= 1e-3
 
 
 def test_pers2equi_conf_vs_oracle():
@@ -191,7 +193,9 @@ def test_properties_full_size():
     # round trip ERP -> patches -> ERP of a smooth panorama stays close (P vs P-1 pixel-scale quirk)
     xs = t(smooth_erp(22, 1, 1, H, W))
     rt = pers2equi(equi2pers_patches(xs, (80, 80), nrows, (P, P)), (80, 80), nrows, (P, P), (H, W), "r")
-    assert (rt - xs).abs().max().item() < 0.02
+    # (mid-latitudes only: an ERP pole row is one point of the sphere, the synthetic image is not
+    #  constant along it; the oracle's own round trip gives 0.0154 here and 0.53 at the pole rows)
+    assert (rt - xs)[:, :, 64:448].abs().max().item() < 0.02
 
 
 def test_high_res_config5_shape_fp16():
@@ -224,6 +228,13 @@ def test_edge_cases_and_errors():
     ref2, _, _, _ = co.equi2pers(x[:1], 80, 5, (9, 15))
     got2 = equi2pers_patches(t(x[:1]), 80, 5, (9, 15), layout=L.LAYOUT_BNCHW).permute(0, 2, 3, 4, 1)
     assert_close_outliers(got2.cpu().numpy(), ref2, tol=1e-3, max_tol=5e-2, frac=1e-3)
+    # quirk q4: both patch dims odd -> the reference's centre sample has lat = 0/0 = NaN, reads the top
+    # ERP row and yields NaN rays (pinned against the reference itself in test_oracle_golden.py)
+    ref3, rxyz3, _, _ = co.equi2pers(x[:1], 80, 4, (9, 9))
+    got3, xyz3, _, _ = equi2pers(t(x[:1]), 80, 4, (9, 9))
+    assert_close_outliers(got3.cpu().numpy(), ref3, tol=1e-3, max_tol=5e-2, frac=1e-3)
+    assert np.isnan(rxyz3[:, :, 4, 4]).all() and torch.isnan(xyz3[:, :, 4, 4]).all()
+    assert int(torch.isnan(xyz3).sum()) == int(np.isnan(rxyz3).sum()) == 18 * 3
     # errors: bad nrows / CPU tensor / wrong patch count / requires_grad
     with pytest.raises(ValueError):
         equi2pers(t(x), 80, 7, 16)

@@ -20,6 +20,8 @@
 // over all B*C image planes, so geometry is evaluated once and amortised; ERP reads are
 // 4-byte gathers with wave-level locality (a wave walks a short curve on the ERP), patch
 // writes are fully coalesced.  HBM-bound: algorithmic bytes B*C*(H*W + ph*pw*N)*sizeof(T).
+#include <stdio.h>
+#include <stdlib.h>
 #include "omni_internal.h"
 
 namespace {
@@ -144,20 +146,18 @@ __device__ __forceinline__ float e2p_fetch(const T* __restrict__ img, const Tap&
 // l, l+64, l+128, l+192 of them, so every load instruction covers 64 CONSECUTIVE samples (a short
 // run of the ERP: 3-4 cache lines per tap row) and every store instruction writes one contiguous
 // 256-byte run.  Geometry is evaluated once per sample and amortised over all B*C image planes.
-constexpr int E2P_SPT = 4;                        // samples per thread
-
-template <typename T, bool PAIR>
+template <typename T, bool PAIR, int SPT, int UNR>
 __global__ __launch_bounds__(256) void e2p_planar_kernel(E2PArgs a, int blocks_per_patch, int nblocks)
 {
     const unsigned lb = omni_xcd_remap(blockIdx.x, nblocks);
     const int n = lb / blocks_per_patch;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e0 = ((lb % blocks_per_patch) * 4 + wave) * (64 * E2P_SPT) + lane;
+    const int e0 = ((lb % blocks_per_patch) * 4 + wave) * (64 * SPT) + lane;
     const int plane = a.ph * a.pw;
     if (e0 >= plane) return;
-    Tap tp[E2P_SPT];
+    Tap tp[SPT];
 #pragma unroll
-    for (int k = 0; k < E2P_SPT; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         const int e = min(e0 + 64 * k, plane - 1);
         tp[k] = e2p_tap<PAIR>(a, n, e / a.pw, e % a.pw);
     }
@@ -165,17 +165,27 @@ __global__ __launch_bounds__(256) void e2p_planar_kernel(E2PArgs a, int blocks_p
     T* out = (T*)a.pers + (size_t)n * a.C * plane + e0;
     const size_t img_plane = (size_t)a.H * a.W;
     const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
-    for (int b = 0; b < a.B; ++b) {
-#pragma unroll 2
-        for (int c = 0; c < a.C; ++c) {
-            const T* img = erp + ((size_t)b * a.C + c) * img_plane;
-            T* dst = out + (size_t)b * out_bstride + (size_t)c * plane;
-            float r[E2P_SPT];
+    const int planes = a.B * a.C;
+    // UNR image planes per trip: all their gathers are issued before the first result is consumed
+    for (int p0 = 0; p0 < planes; p0 += UNR) {
+        float r[UNR][SPT];
 #pragma unroll
-            for (int k = 0; k < E2P_SPT; ++k) r[k] = e2p_fetch<T, PAIR>(img, tp[k]);
+        for (int u = 0; u < UNR; ++u) {
+            const int p = min(p0 + u, planes - 1);
+            const T* img = erp + (size_t)p * img_plane;
 #pragma unroll
-            for (int k = 0; k < E2P_SPT; ++k)
-                if (e0 + 64 * k < plane) Store<T>::st(dst + 64 * k, r[k]);
+            for (int k = 0; k < SPT; ++k) r[u][k] = e2p_fetch<T, PAIR>(img, tp[k]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int p = p0 + u;
+            if (p < planes) {
+                const int b = p / a.C, c = p - b * a.C;
+                T* dst = out + (size_t)b * out_bstride + (size_t)c * plane;
+#pragma unroll
+                for (int k = 0; k < SPT; ++k)
+                    if (e0 + 64 * k < plane) Store<T>::st(dst + 64 * k, r[u][k]);
+            }
         }
     }
 }
@@ -284,11 +294,23 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
     const int plane = g->ph * g->pw, N = g->N;
     const bool pair = g->W >= 2;
     if (layout == OMNI_LAYOUT_BNCHW) {
-        const int per_block = 256 * E2P_SPT;
+        int spt = 2, unr = 3;
+        if (const char* v = getenv("OMNI_E2P_VAR")) sscanf(v, "%d,%d", &spt, &unr);      // tuning hook
+        const int per_block = 256 * spt;
         const int bpp = (plane + per_block - 1) / per_block;
         const int nblocks = N * bpp;
-        if (pair) hipLaunchKernelGGL((e2p_planar_kernel<T, true>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
-        else      hipLaunchKernelGGL((e2p_planar_kernel<T, false>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks);
+#define E2P_LAUNCH(S, U)                                                                                      \
+        do { if (pair) hipLaunchKernelGGL((e2p_planar_kernel<T, true, S, U>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks); \
+             else      hipLaunchKernelGGL((e2p_planar_kernel<T, false, S, U>), dim3(nblocks), dim3(256), 0, stream, a, bpp, nblocks); } while (0)
+        if (spt == 4 && unr == 1) E2P_LAUNCH(4, 1);
+        else if (spt == 4 && unr == 3) E2P_LAUNCH(4, 3);
+        else if (spt == 2 && unr == 1) E2P_LAUNCH(2, 1);
+        else if (spt == 2 && unr == 3) E2P_LAUNCH(2, 3);
+        else if (spt == 1 && unr == 3) E2P_LAUNCH(1, 3);
+        else if (spt == 1 && unr == 6) E2P_LAUNCH(1, 6);
+        else if (spt == 2 && unr == 6) E2P_LAUNCH(2, 6);
+        else OMNI_FAIL(OMNI_ERR_INVALID, "bad OMNI_E2P_VAR");
+#undef E2P_LAUNCH
     } else if (layout == OMNI_LAYOUT_BCHWN) {
         const int tiles_w = (g->pw + E2P_TW - 1) / E2P_TW;
         const size_t lds = sizeof(float) * E2P_CCH * E2P_TW * N;

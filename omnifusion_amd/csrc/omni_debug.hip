@@ -1,0 +1,44 @@
+// omni_debug.hip — micro-benchmarks used while tuning (not part of the product path).
+#include "omni_internal.h"
+
+namespace {
+// mode 0: dword stores, lane-contiguous (256 B per wave-instruction), 4 per thread at stride 64
+// mode 1: one 16-byte store per thread (1 KiB per wave-instruction)
+// mode 2: like 0 but each wave-instruction writes two separate 128-B rows (32x32 tile pattern)
+template <int MODE>
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, size_t n, int planes, size_t pstride, float v)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = 0; q < planes; ++q) {
+        float* d = p + (size_t)q * pstride;
+        if (MODE == 0) {
+            const size_t e0 = ((size_t)blockIdx.x * 4 + wave) * 256 + lane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (e0 + 64 * k < n) d[e0 + 64 * k] = v + (float)k;
+        } else if (MODE == 1) {
+            if (t * 4 + 3 < n) *reinterpret_cast<float4*>(d + t * 4) = make_float4(v, v + 1.f, v + 2.f, v + 3.f);
+        } else {
+            // 32x32 tile of a 256-wide plane: thread -> col = t&31, row = (t>>5) + 8k
+            const int tile = blockIdx.x, tx = tile & 7, ty = tile >> 3;
+            const int col = threadIdx.x & 31, rowb = threadIdx.x >> 5;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t e = (size_t)(ty * 32 + rowb + 8 * k) * 256 + tx * 32 + col;
+                if (e < n) d[e] = v + (float)k;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int omni_debug_fill(float* p, size_t n_per_plane, int planes, int mode, omni_stream_t stream)
+{
+    const int blocks = (int)((n_per_plane + 1023) / 1024);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(fill_kernel<0>, dim3(blocks), dim3(256), 0, s, p, n_per_plane, planes, n_per_plane, 1.0f);
+    else if (mode == 1) hipLaunchKernelGGL(fill_kernel<1>, dim3(blocks), dim3(256), 0, s, p, n_per_plane, planes, n_per_plane, 1.0f);
+    else hipLaunchKernelGGL(fill_kernel<2>, dim3(blocks), dim3(256), 0, s, p, n_per_plane, planes, n_per_plane, 1.0f);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

@@ -22,6 +22,8 @@
 // writes are fully coalesced.  HBM-bound: algorithmic bytes B*C*(H*W + ph*pw*N)*sizeof(T).
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <vector>
 #include "omni_internal.h"
 
 namespace {
@@ -32,6 +34,7 @@ struct E2PArgs {
     float fovx, fovy;          // fov_w/360, fov_h/180  (equi2pers_v3.py:24)
     float stepx, stepy;        // linspace(0,1,P) step (:29)
     float sx_scale, sy_scale;  // (W-1)/2, (H-1)/2  (grid_sample align_corners=True)
+    int dbg;                   // tuning hook (OMNI_E2P_DBG): 1 = suppress stores, 2 = suppress box loads
     PatchTab tab;
 };
 
@@ -190,6 +193,199 @@ __global__ __launch_bounds__(256) void e2p_planar_kernel(E2PArgs a, int blocks_p
     }
 }
 
+// ------------------------------------------------------------------ planar output, LDS-staged ERP footprint
+// The gather kernel above is bound by the vector L1: a 64-lane gather costs ~27 tag look-ups for ~0.5 KB of
+// useful data (profiles/r01a_resample_pmc.txt).  Here a block owns a 32x32 sample tile of one patch, finds the
+// bounding box of the tile's bilinear footprint on the ERP (block reduction; columns measured relative to the
+// tile's first sample so that a tile straddling the +-pi seam still has a narrow box), streams that box into
+// LDS with fully coalesced 16-byte loads (64 useful bytes per L1 access) and takes the four taps of every
+// sample from LDS (ds_read2_b32).  The box of plane p+1 is in flight in registers while plane p is computed
+// (double-buffered LDS, one barrier per plane).  Tiles whose box does not fit (the pole itself lies inside, or
+// the ERP row pitch is not a multiple of 4) fall back to the direct gathers — wave-uniform branch, same taps.
+constexpr int E2P_TS = 32;                        // tile side (samples)
+constexpr int E2P_BOXF = 3968;                    // floats per LDS buffer: 2 buffers + 80 B < 32 KiB -> 5 blocks / CU
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+
+// Grid: blocks [0, ntiles) own one (patch, tile) each and run the LDS path; a tile that does not fit returns at once
+// and is covered by blocks [ntiles, ntiles + nfb*B): one block per (listed tile, batch item), direct gathers, so the
+// few pole tiles are spread over B times more blocks instead of serialising B*C planes in one straggler.
+// flags_out != nullptr: geometry-setup mode, only records which tiles need the gather path.
+__global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, int tiles_per_patch, int ntiles,
+                                                      const int* __restrict__ fb, unsigned char* flags_out)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float box[2][E2P_BOXF];
+    __shared__ int red[4][4];
+    __shared__ int sh_xc;
+    const bool fb_block = (int)blockIdx.x >= ntiles;
+    int fb_b = 0;
+    unsigned lb;
+    if (fb_block) { const int idx = blockIdx.x - ntiles; lb = fb[idx / a.B]; fb_b = idx % a.B; }
+    else lb = omni_xcd_remap(blockIdx.x, ntiles);
+    const int n = lb / tiles_per_patch;
+    const int tile = lb % tiles_per_patch;
+    const int th0 = (tile / tiles_x) * E2P_TS, tw0 = (tile % tiles_x) * E2P_TS;
+    const int t = threadIdx.x, wave = t >> 6;
+    const int col = t & 31, rowb = t >> 5;
+    const int W = a.W, H = a.H;
+
+    // ---- taps of this thread's 4 samples (rows rowb + 8k of the tile, column col)
+    int x0[4], y0[4], y1[4], s1[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    const int w = min(tw0 + col, a.pw - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = min(th0 + rowb + 8 * k, a.ph - 1);
+        float lon, lat, x, q, tt, inv, u, v;
+        e2p_lonlat(a, n, h, w, lon, lat, x, q, tt, inv);
+        e2p_uv(lon, lat, u, v);
+        float ix = (u + 1.0f) * a.sx_scale, iy = (v + 1.0f) * a.sy_scale;
+        ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+        iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+        const float fx = floorf(ix), fy = floorf(iy);
+        x0[k] = (int)fx; y0[k] = (int)fy;
+        const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
+        w00[k] = ey * ex; w01[k] = ey * tx; w10[k] = ty * ex; w11[k] = ty * tx;
+        y1[k] = min(y0[k] + 1, H - 1);
+        s1[k] = (x0[k] + 1 < W) ? 1 : 0;          // +1 column outside: alias onto x0 (its weight is exactly 0)
+    }
+    // ---- footprint box: rows [ymin, ymax], columns relative to the tile's first sample (seam-safe)
+    if (t == 0) sh_xc = x0[0];
+    __syncthreads();
+    const int xc = sh_xc, half = W >> 1;
+    int dx[4];
+    int ymin = y0[0], ymax = y1[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int d = x0[k] - xc;
+        if (d >= half) d -= W;
+        if (d < -half) d += W;
+        dx[k] = d;
+        ymin = min(ymin, y0[k]); ymax = max(ymax, y1[k]);
+    }
+    int dmin = min(min(dx[0], dx[1]), min(dx[2], dx[3]));
+    int dmax = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
+    ymin = wave_min(ymin); ymax = wave_max(ymax); dmin = wave_min(dmin); dmax = wave_max(dmax);
+    if ((t & 63) == 0) { red[wave][0] = ymin; red[wave][1] = ymax; red[wave][2] = dmin; red[wave][3] = dmax; }
+    __syncthreads();
+    ymin = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    ymax = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+    dmin = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+    dmax = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    int xs = xc + dmin;                             // absolute first column of the box (may wrap)
+    if (xs < 0) xs += W;
+    if (xs >= W) xs -= W;
+    const int xs4 = xs & ~3, shift = xs - xs4;
+    const int bw = (dmax - dmin + 2 + shift + 3) & ~3;       // columns x0..x0+1 of every sample, whole 16-byte chunks
+    const int bh = ymax - ymin + 1;
+    const int bw4 = bw >> 2, nchunk = bh * bw4;
+    const bool fits = ((W & 3) == 0) && (bw <= W) && (bh * bw <= E2P_BOXF);
+    const bool full = (th0 + E2P_TS <= a.ph) && (tw0 + E2P_TS <= a.pw);
+
+    const float* erp = (const float*)a.erp;
+    const int plane = a.ph * a.pw;
+    const size_t img_plane = (size_t)H * W;
+    const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
+    // this thread's 4 output elements: e0 + 8k rows
+    float* out = (float*)a.pers + (size_t)n * a.C * plane + (size_t)(th0 + rowb) * a.pw + (tw0 + col);
+    const int ostep = 8 * a.pw;
+
+    if (flags_out) { if (t == 0) flags_out[lb] = (fits && full) ? 0 : 1; return; }
+    if (!fb_block && !(fits && full)) return;          // covered by the fallback blocks of this launch
+    if (!fb_block) {
+        int r0[4], r1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c0 = dx[k] - dmin + shift;
+            r0[k] = (y0[k] - ymin) * bw + c0;
+            r1[k] = (y1[k] - ymin) * bw + c0;
+        }
+        // Plane loop for a box of NJ x 256 16-byte chunks at most (NJ is block-uniform).  Threads past the
+        // last chunk re-load / re-store the last chunk (identical data, same address): no exec masking.
+        auto run = [&](auto NJc) {
+            constexpr int NJ = decltype(NJc)::value;
+            int goff[NJ], lidx[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int qd = min(t + 256 * j, nchunk - 1);
+                const int r = qd / bw4, cx = qd - r * bw4;
+                int gx = xs4 + 4 * cx;
+                if (gx >= W) gx -= W;
+                goff[j] = (ymin + r) * W + gx;
+                lidx[j] = qd;
+            }
+            f4v pf[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pf[j] = *reinterpret_cast<const f4v*>(erp + goff[j]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) reinterpret_cast<f4v*>(box[0])[lidx[j]] = pf[j];
+            __syncthreads();
+            const float* img = erp;
+            float* dst = out;
+            int par = 0;
+            for (int b = 0; b < a.B; ++b) {
+                for (int c = 0; c < a.C; ++c) {
+                    const float* cur = box[par];
+                    float* nxt = box[par ^ 1];
+                    par ^= 1;
+                    const bool last = (b == a.B - 1) && (c == a.C - 1);
+                    if (!last) img += img_plane;                     // the last trip re-reads its own plane
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) if (!(a.dbg & 2)) pf[j] = *reinterpret_cast<const f4v*>(img + goff[j]);
+                    float v00[4], v01[4], v10[4], v11[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v00[k] = cur[r0[k]]; v01[k] = cur[r0[k] + s1[k]];
+                        v10[k] = cur[r1[k]]; v11[k] = cur[r1[k] + s1[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float r = fmaf(v11[k], w11[k], fmaf(v10[k], w10[k], fmaf(v01[k], w01[k], v00[k] * w00[k])));
+                        if (!(a.dbg & 1) || r == 12345.678f) dst[k * ostep] = r;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) reinterpret_cast<f4v*>(nxt)[lidx[j]] = pf[j];
+                    __syncthreads();
+                    dst += plane;
+                }
+                dst += out_bstride - (size_t)a.C * plane;
+            }
+        };
+        if (nchunk <= 256)      run(std::integral_constant<int, 1>{});
+        else if (nchunk <= 512) run(std::integral_constant<int, 2>{});
+        else if (nchunk <= 768) run(std::integral_constant<int, 3>{});
+        else                    run(std::integral_constant<int, 4>{});
+    } else {
+        // direct gathers (same taps): tiles containing a pole, ragged tiles, odd row pitch
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok[k] = (th0 + rowb + 8 * k < a.ph) && (tw0 + col < a.pw);
+        float* dstb = out + (size_t)fb_b * out_bstride;
+        for (int c = 0; c < a.C; ++c) {
+            const float* img = erp + ((size_t)fb_b * a.C + c) * img_plane;
+            float* dst = dstb + (size_t)c * plane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g0 = y0[k] * W + x0[k], g1 = y1[k] * W + x0[k];
+                const float v00 = img[g0], v01 = img[g0 + s1[k]], v10 = img[g1], v11 = img[g1 + s1[k]];
+                const float r = fmaf(v11, w11[k], fmaf(v10, w10[k], fmaf(v01, w01[k], v00 * w00[k])));
+                if (ok[k]) dst[k * ostep] = r;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ reference output [B,C,ph,pw,N]
 // A block owns one patch row h and TW = 64 columns for ALL N patches.  Wave v gathers patches
 // v, v+4, ... with lane <-> w (good ERP locality), parks the results in an LDS tile laid out
@@ -285,8 +481,35 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
     a.stepy = g->ph > 1 ? 1.0f / (float)(g->ph - 1) : 0.0f;
     a.sx_scale = (float)(g->W - 1) / 2.0f; a.sy_scale = (float)(g->H - 1) / 2.0f;
     a.tab = g->e2p;
+    const char* d = getenv("OMNI_E2P_DBG"); a.dbg = d ? atoi(d) : 0;
 }
 
+}  // namespace
+
+int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream)
+{
+    E2PArgs a; fill_args(a, g, nullptr, nullptr, 1, 1);
+    const int tx = (g->pw + E2P_TS - 1) / E2P_TS, ty = (g->ph + E2P_TS - 1) / E2P_TS;
+    const int nt = g->N * tx * ty;
+    unsigned char* dflags = nullptr;
+    OMNI_HIP(hipMalloc((void**)&dflags, nt));
+    hipLaunchKernelGGL(e2p_lds_kernel, dim3(nt), dim3(256), 0, stream, a, tx, tx * ty, nt, (const int*)nullptr, dflags);
+    OMNI_HIP(hipGetLastError());
+    std::vector<unsigned char> hf(nt);
+    OMNI_HIP(hipMemcpyAsync(hf.data(), dflags, nt, hipMemcpyDeviceToHost, stream));
+    OMNI_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(dflags);
+    std::vector<int> list;
+    for (int i = 0; i < nt; ++i) if (hf[i]) list.push_back(i);
+    g->e2p_nfb = (int)list.size();
+    if (!list.empty()) {
+        OMNI_HIP(hipMalloc((void**)&g->e2p_fb_tiles, sizeof(int) * list.size()));
+        OMNI_HIP(hipMemcpy(g->e2p_fb_tiles, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+    }
+    return OMNI_OK;
+}
+
+namespace {
 template <typename T>
 int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C, int layout, hipStream_t stream)
 {
@@ -295,7 +518,16 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
     const bool pair = g->W >= 2;
     if (layout == OMNI_LAYOUT_BNCHW) {
         int spt = 2, unr = 3;
-        if (const char* v = getenv("OMNI_E2P_VAR")) sscanf(v, "%d,%d", &spt, &unr);      // tuning hook
+        const char* var = getenv("OMNI_E2P_VAR");                                        // tuning hook
+        if (var) sscanf(var, "%d,%d", &spt, &unr);
+        if (sizeof(T) == 4 && !var && g->W >= 2) {
+            const int tx = (g->pw + E2P_TS - 1) / E2P_TS, ty = (g->ph + E2P_TS - 1) / E2P_TS;
+            const int nt = N * tx * ty;
+            hipLaunchKernelGGL(e2p_lds_kernel, dim3(nt + g->e2p_nfb * B), dim3(256), 0, stream, a, tx, tx * ty, nt,
+                               (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
+            OMNI_HIP(hipGetLastError());
+            return OMNI_OK;
+        }
         const int per_block = 256 * spt;
         const int bpp = (plane + per_block - 1) / per_block;
         const int nblocks = N * bpp;

@@ -111,6 +111,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     g->N = g->e2p.N;
     centers(nrows, 0, nullptr, nullptr, g->center_p);
     g->row_trig = nullptr; g->col_trig = nullptr; g->cand = nullptr; g->ntx = (W + 63) / 64;
+    g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0;
 
     if (H > 0 && W > 0) {
         const float PI_F = (float)M_PI, PI_2_F = (float)(M_PI * 0.5);
@@ -124,6 +125,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
         OMNI_HIP(hipMemcpy(g->row_trig, rt.data(), sizeof(float2) * H, hipMemcpyHostToDevice));
         OMNI_HIP(hipMemcpy(g->col_trig, ct.data(), sizeof(float2) * W, hipMemcpyHostToDevice));
         int rc = omni_p2e_build_candidates(g.get(), stream);
+        if (rc == OMNI_OK) rc = omni_e2p_build_tileflags(g.get(), stream);
         if (rc != OMNI_OK) { omni_geometry_destroy(g.release()); return rc; }
     }
     *out = g.release();
@@ -136,6 +138,7 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->row_trig) (void)hipFree(g->row_trig);
     if (g->col_trig) (void)hipFree(g->col_trig);
     if (g->cand) (void)hipFree(g->cand);
+    if (g->e2p_fb_tiles) (void)hipFree(g->e2p_fb_tiles);
     delete g;
 }
 

@@ -42,6 +42,8 @@ struct omni_geometry {
     float2* col_trig;              // [W]  (sin lon_j, cos lon_j)
     unsigned long long* cand;      // [H][ntx] bit n set <=> patch n covers >=1 pixel of the 64-px tile
     int ntx;
+    int* e2p_fb_tiles;             // equi2pers: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box
+    int e2p_nfb;
 };
 
 // implemented in omni_geometry.hip
@@ -49,6 +51,8 @@ int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, floa
                          int ph, int pw, int H, int W, hipStream_t stream);
 // implemented in omni_pers2equi.hip: fills g->cand on `stream`
 int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream);
+// implemented in omni_equi2pers.hip: fills g->e2p_fb_tiles / e2p_nfb
+int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream);
 
 // ---------------------------------------------------------------- storage types
 template <typename T> struct Store;

@@ -110,6 +110,47 @@ int omni_equi2pers_g(const omni_geometry_t* g, const void* erp, void* pers, int 
 int omni_pers2equi_g(const omni_geometry_t* g, const void* pers, void* erp, int dtype, int B, int C,
                      int layout, omni_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Network operators (rows a3-a8 of SURVEY.md 8a).  Activations are NHWC fp32 over M = B*N patches
+ * ([M,H,W,C]); eval-mode BatchNorm is folded into the weights by the caller at load time.  The
+ * reference runs these as Conv3d(k,k,1)/BatchNorm3d/Linear modules over [B,C,P,P,N] tensors.
+ * ---------------------------------------------------------------------------------------------- */
+enum omni_act { OMNI_ACT_NONE = 0, OMNI_ACT_RELU = 1, OMNI_ACT_GELU = 2 };
+
+/* dst[M,Ho,Wo,Cout] = act(conv(src1 ++ src2 (channel concat), wt) + bias + res) on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32).  wt: [Cout][KH*KW*(C1+C2)], k ordered (ky,kx,c).  C1,C2,Cout multiples of 32.
+ * Replaces: encoder BasicBlock convs model/spherical_model.py:122-167,257-261 (residual+ReLU fused), decoder
+ * ConvBnReLU_v2 :29-37,274-302 incl. torch.cat :275,282,289,296, `down` :211,263, and every nn.Linear of
+ * model/blocks.py:19-21,43-46 (H=W=KH=KW=1; GELU of :20 and the residual adds of :86-87 fused). */
+int omni_conv2d_nhwc_f32(const float* src1, const float* src2, const float* wt, const float* bias,
+                         const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                         int KH, int KW, int stride, int pad, int act, omni_stream_t stream);
+/* conv1 7x7 s2 p3 (3->64) + bn1 + ReLU, model/spherical_model.py:254.  src planar [M,3,P,P]
+ * (OMNI_LAYOUT_BNCHW patches), wt [147][64] (k = (ky*7+kx)*3+c), dst NHWC [M,P/2,P/2,64]. */
+int omni_stem_f32(const float* src, const float* wt, const float* bias, float* dst, int M, int P, omni_stream_t stream);
+/* F.max_pool3d((3,3,1),(2,2,1),(1,1,0)), model/spherical_model.py:255 */
+int omni_maxpool3x3s2_f32(const float* src, float* dst, int M, int H, int W, int C, omni_stream_t stream);
+/* F.interpolate(bilinear, align_corners=False), model/spherical_model.py:271,279,286,293,300 */
+int omni_upsample_bilinear_f32(const float* src, float* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream);
+/* x[m,hw,c] += y[m,c]: the transformer token added as a channel bias, model/spherical_model.py:267-268 */
+int omni_add_hw_f32(float* x, const float* y, int M, int HW, int C, omni_stream_t stream);
+/* x[i] += y[i % period]: layer1 + point_feat, model/spherical_model.py:258 */
+int omni_add_period_f32(float* x, const float* y, size_t total, size_t period, omni_stream_t stream);
+/* tokens: reshape(bs,-1,N).transpose(1,2) of the `down` output + pos_emb, model/spherical_model.py:264,181 */
+int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream);
+/* nn.LayerNorm(512), model/blocks.py:74,81 (eps 1e-5) and model/spherical_model.py:173 (eps 1e-6) */
+int omni_layernorm512_f32(const float* x, const float* g, const float* b, float* y, int rows, float eps, omni_stream_t stream);
+/* softmax(q k^T * 128^-1/2) v, 4 heads x 128 over N <= 64 tokens, model/blocks.py:52-62.  q [B*N,512], kv [B*N,1024] */
+int omni_attention_f32(const float* q, const float* kv, float* out, int B, int N, omni_stream_t stream);
+/* pred (ReLU) and weight_pred (sigmoid) 3x3 heads, model/spherical_model.py:304-307.  x NHWC [M,P,P,32], w [2][9][32];
+ * out_a = relu(pred) * (confidence ? sigmoid(weight) : 1), out_c = sigmoid(weight) (may be NULL); planar [M,P,P] */
+int omni_heads_f32(const float* x, const float* w, float bias_pred, float bias_weight, float* out_a, float* out_c,
+                   int M, int P, int confidence, omni_stream_t stream);
+/* mlp_points1 / mlp_points2 (1x1 conv 3->16->64, BN folded, ReLU) of xyz[N,3,HW] (* depth[Mo,HW] if non-NULL),
+ * model/spherical_model_iterative.py:290-305,319,387-393.  out NHWC [Mo,HW,64]. */
+int omni_mlp_points_f32(const float* xyz, const float* depth, const float* w1, const float* b1, const float* w2,
+                        const float* b2, float* out, int Mo, int N, int HW, omni_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

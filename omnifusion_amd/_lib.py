@@ -28,6 +28,9 @@ EXPORTS = [
     "omni_geometry_create", "omni_geometry_destroy", "omni_geometry_cache_clear",
     "omni_equi2pers", "omni_equi2pers_aux", "omni_pers2equi", "omni_pers2equi_conf",
     "omni_equi2pers_g", "omni_pers2equi_g",
+    "omni_conv2d_nhwc_f32", "omni_stem_f32", "omni_maxpool3x3s2_f32", "omni_upsample_bilinear_f32",
+    "omni_add_hw_f32", "omni_add_period_f32", "omni_token_pack_f32", "omni_layernorm512_f32",
+    "omni_attention_f32", "omni_heads_f32", "omni_mlp_points_f32",
 ]
 
 

@@ -1,0 +1,246 @@
+"""Host-side engine of the network: weight packing (BN folding, NHWC-GEMM layouts) and the launch
+sequence of one forward over the C-ABI operators of libomnifusion_hip.so.
+
+Everything numeric runs in the HIP library; PyTorch only owns the device buffers (caching
+allocator), the stream and — once per `load_state_dict` — the constant folding of the weights
+(BatchNorm -> conv, the input-independent `mlp_points` branch of the single-pass model).
+
+Reference: model/spherical_model.py:238-314 (single pass), model/spherical_model_iterative.py:308-456.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..equi_pers.equi2pers_v3 import equi2pers_patches, equi2pers_aux, pair, _NPATCH
+from ..equi_pers.pers2equi_v3 import pers2equi, pers2equi_conf
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+_LAYERS = [("layer1", 3, 1), ("layer2", 4, 2), ("layer3", 6, 2), ("layer4", 3, 2)]
+_BN_EPS = 1e-5
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def strip_module_prefix(sd):
+    """checkpoints saved through nn.DataParallel carry a 'module.' prefix (train_erp_depth.py:307)"""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+class Engine:
+    def __init__(self, nrows, npatches, patch_size, fov, iterative):
+        self.nrows, self.npatches, self.iterative = nrows, npatches, iterative
+        self.patch_size = pair(patch_size)
+        self.fov = pair(fov)
+        if self.patch_size[0] != self.patch_size[1]:
+            raise ValueError("square patches only")
+        self.w = None          # packed weights (device tensors)
+        self.device = None
+
+    # ------------------------------------------------------------------ packing
+    @staticmethod
+    def _fold(sd, conv, bn):
+        w = sd[conv + ".weight"].double()
+        if w.dim() == 5:
+            w = w[..., 0]
+        g = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + _BN_EPS)
+        b = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * g
+        return w * g[:, None, None, None], b
+
+    @staticmethod
+    def _gemm_layout(w):
+        # [O, I, kh, kw] -> [O][kh*kw*I] with k = (ky, kx, c)
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+    def pack(self, state_dict, device):
+        sd = {k: v.detach().cpu() for k, v in strip_module_prefix(state_dict).items()}
+        dev = torch.device(device)
+        f = lambda t: t.to(torch.float32).contiguous().to(dev)
+        W = {}
+        w, b = self._fold(sd, "conv1", "bn1")                                    # stem: [147][64], k = (ky*7+kx)*3 + c
+        W["stem.w"] = f(w.permute(2, 3, 1, 0).reshape(147, 64)); W["stem.b"] = f(b)
+
+        def convbn(key, conv, bn):
+            w, b = self._fold(sd, conv, bn)
+            W[key + ".w"] = f(self._gemm_layout(w)); W[key + ".b"] = f(b)
+        for lname, nblk, _ in _LAYERS:
+            for i in range(nblk):
+                p = f"{lname}.{i}"
+                convbn(p + ".c1", p + ".conv1", p + ".bn1")
+                convbn(p + ".c2", p + ".conv2", p + ".bn2")
+                if (p + ".downsample.0.weight") in sd:
+                    convbn(p + ".ds", p + ".downsample.0", p + ".downsample.1")
+        for name in ("de_conv0_0", "de_conv0_1", "de_conv1_0", "de_conv1_1", "de_conv2_0", "de_conv2_1",
+                     "de_conv3_0", "de_conv3_1", "de_conv4_0"):
+            convbn(name, name + ".conv", name + ".bn")
+        down = "down1" if self.iterative else "down"
+        W["down.w"] = f(sd[down + ".weight"].reshape(32, 512)); W["down.b"] = f(sd[down + ".bias"])
+        W["pos"] = f(sd["transformer.pos_emb"].reshape(self.npatches, 512))
+        for i in range(6):
+            p = f"transformer.layer.{i}"
+            for k in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.q.weight", "attn.kv.weight",
+                      "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"):
+                W[f"t{i}.{k}"] = f(sd[f"{p}.{k}"])
+        W["enc_norm.w"] = f(sd["transformer.encoder_norm.weight"]); W["enc_norm.b"] = f(sd["transformer.encoder_norm.bias"])
+        hw = torch.stack([sd["pred.weight"][0, :, :, :, 0], sd["weight_pred.weight"][0, :, :, :, 0]])    # [2,32,3,3]
+        W["heads.w"] = f(hw.permute(0, 2, 3, 1).reshape(2, 9, 32))
+        self.head_bias = (float(sd["pred.bias"][0]), float(sd["weight_pred.bias"][0]))
+
+        def mlp(name):
+            w1, b1 = self._fold(sd, name + ".0", name + ".1")
+            w2, b2 = self._fold(sd, name + ".3", name + ".4")
+            return w1[:, :, 0, 0], b1, w2[:, :, 0, 0], b2
+        P4 = self.patch_size[0] // 4
+        if self.iterative:
+            for name in ("mlp_points1", "mlp_points2"):
+                w1, b1, w2, b2 = mlp(name)
+                W[name + ".w1"], W[name + ".b1"], W[name + ".w2"], W[name + ".b2"] = f(w1), f(b1), f(w2), f(b2)
+        else:
+            # single pass: the input of mlp_points is [cx, cy, 1, cx, cy] broadcast over the patch
+            # (spherical_model.py:245-251) — a constant of the weights: fold it to one vector per patch.
+            cp = (ctypes.c_float * (2 * self.npatches))()
+            _lib.check(_lib.load().omni_patch_centers(int(self.nrows), 0, cp), "patch_centers")
+            c = torch.tensor(list(cp), dtype=torch.float64).reshape(self.npatches, 2)
+            x = torch.cat([c, torch.ones(self.npatches, 1, dtype=torch.float64), c], 1)          # [N,5]
+            w1, b1, w2, b2 = mlp("mlp_points")
+            h = torch.relu(x @ w1.T + b1)
+            pf = torch.relu(h @ w2.T + b2)                                                         # [N,64]
+            W["point_feat"] = f(pf[:, None, None, :].expand(self.npatches, P4, P4, 64))
+        self.w, self.device = W, dev
+
+    # ------------------------------------------------------------------ operator shims
+    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True):
+        lib = _lib.load()
+        Ho = (H + 2 * pad - k) // stride + 1
+        Wo = (Wd + 2 * pad - k) // stride + 1
+        out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        rc = lib.omni_conv2d_nhwc_f32(_p(x), _p(x2), _p(self.w[key + ".w"]), _p(self.w[key + ".b"]) if bias else None,
+                                      _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, self._s)
+        _lib.check(rc, "conv2d " + key)
+        return out
+
+    def _gemm(self, x, wkey, bkey, rows, K, Nout, act=ACT_NONE, res=None):
+        lib = _lib.load()
+        out = torch.empty((rows, Nout), dtype=torch.float32, device=x.device)
+        rc = lib.omni_conv2d_nhwc_f32(_p(x), None, _p(self.w[wkey]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
+                                      rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, self._s)
+        _lib.check(rc, "gemm " + wkey)
+        return out
+
+    def _ln(self, x, wk, bk, rows, eps):
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().omni_layernorm512_f32(_p(x), _p(self.w[wk]), _p(self.w[bk]), _p(y), rows, ctypes.c_float(eps), self._s), "layernorm")
+        return y
+
+    def _up(self, x, M, H, Wd, C, Ho, Wo):
+        y = torch.empty((M, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().omni_upsample_bilinear_f32(_p(x), _p(y), M, H, Wd, C, Ho, Wo, self._s), "upsample")
+        return y
+
+    # ------------------------------------------------------------------ network over the patch batch
+    def network(self, patches, point_feat, bs, confidence):
+        """patches: planar [bs, N, 3, P, P]; point_feat: NHWC [N or bs*N, P/4, P/4, 64].
+        Returns (a, c) planar [bs, N, 1, P, P]: a = relu(pred) (* conf), c = sigmoid(weight) or None."""
+        lib = _lib.load()
+        dev = patches.device
+        self._s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        N, P = self.npatches, self.patch_size[0]
+        M = bs * N
+        P2, P4, P8, P16, P32 = P // 2, P // 4, P // 8, P // 16, P // 32
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        conv1 = new(M, P2, P2, 64)
+        _lib.check(lib.omni_stem_f32(_p(patches), _p(self.w["stem.w"]), _p(self.w["stem.b"]), _p(conv1), M, P, self._s), "stem")
+        x = new(M, P4, P4, 64)
+        _lib.check(lib.omni_maxpool3x3s2_f32(_p(conv1), _p(x), M, P2, P2, 64, self._s), "maxpool")
+        feats = {}
+        cin, size = 64, P4
+        for lname, nblk, stride in _LAYERS:
+            cout = {"layer1": 64, "layer2": 128, "layer3": 256, "layer4": 512}[lname]
+            for i in range(nblk):
+                p = f"{lname}.{i}"
+                s = stride if i == 0 else 1
+                ident = x
+                if (p + ".ds.w") in self.w:
+                    ident = self._conv(x, p + ".ds", M, size, size, cin, cout, 1, s, 0, ACT_NONE)
+                y = self._conv(x, p + ".c1", M, size, size, cin, cout, 3, s, 1, ACT_RELU)
+                size = (size + 2 - 3) // s + 1
+                x = self._conv(y, p + ".c2", M, size, size, cout, cout, 3, 1, 1, ACT_RELU, res=ident)
+                cin = cout
+            if lname == "layer1":                                   # layer1 + point_feat (:258)
+                _lib.check(lib.omni_add_period_f32(_p(x), _p(point_feat), ctypes.c_size_t(x.numel()),
+                                                   ctypes.c_size_t(point_feat.numel()), self._s), "add point_feat")
+            feats[lname] = x
+        layer1, layer2, layer3, layer4 = (feats[k] for k in ("layer1", "layer2", "layer3", "layer4"))
+        # ---- transformer over the N tokens of each panorama (:263-268)
+        if 32 * P32 * P32 != 512:
+            raise RuntimeError(f"patch size {P}: token dim {32 * P32 * P32} != 512 — the reference network only exists at "
+                               "patch size 128 (SURVEY.md finding 0.1)")
+        d = self._conv(layer4, "down", M, P32, P32, 512, 32, 1, 1, 0, ACT_NONE)
+        tok = new(M, 512)
+        _lib.check(lib.omni_token_pack_f32(_p(d), _p(self.w["pos"]), _p(tok), M, N, P32 * P32, 32, self._s), "token_pack")
+        for i in range(6):
+            t = f"t{i}."
+            y = self._ln(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)
+            q = self._gemm(y, t + "attn.q.weight", None, M, 512, 512)
+            kv = self._gemm(y, t + "attn.kv.weight", None, M, 512, 1024)
+            att = new(M, 512)
+            _lib.check(lib.omni_attention_f32(_p(q), _p(kv), _p(att), bs, N, self._s), "attention")
+            tok = self._gemm(att, t + "attn.proj.weight", t + "attn.proj.bias", M, 512, 512, res=tok)
+            y = self._ln(tok, t + "norm2.weight", t + "norm2.bias", M, 1e-5)
+            h = self._gemm(y, t + "mlp.fc1.weight", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU)
+            tok = self._gemm(h, t + "mlp.fc2.weight", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
+        tok = self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
+        _lib.check(lib.omni_add_hw_f32(_p(layer4), _p(tok), M, P32 * P32, 512, self._s), "token bias")
+        # ---- decoder (:270-302); torch.cat is the two-source form of the conv
+        up = self._up(layer4, M, P32, P32, 512, P16, P16)
+        x = self._conv(up, "de_conv0_0", M, P16, P16, 512, 256, 3, 1, 1, ACT_RELU)
+        x = self._conv(x, "de_conv0_1", M, P16, P16, 256, 128, 3, 1, 1, ACT_RELU, x2=layer3, C2=256)
+        up = self._up(x, M, P16, P16, 128, P8, P8)
+        x = self._conv(up, "de_conv1_0", M, P8, P8, 128, 128, 3, 1, 1, ACT_RELU)
+        x = self._conv(x, "de_conv1_1", M, P8, P8, 128, 64, 3, 1, 1, ACT_RELU, x2=layer2, C2=128)
+        up = self._up(x, M, P8, P8, 64, P4, P4)
+        x = self._conv(up, "de_conv2_0", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU)
+        x = self._conv(x, "de_conv2_1", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU, x2=layer1, C2=64)
+        up = self._up(x, M, P4, P4, 64, P2, P2)
+        x = self._conv(up, "de_conv3_0", M, P2, P2, 64, 64, 3, 1, 1, ACT_RELU)
+        x = self._conv(x, "de_conv3_1", M, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1, C2=64)
+        up = self._up(x, M, P2, P2, 32, P, P)
+        x = self._conv(up, "de_conv4_0", M, P, P, 32, 32, 3, 1, 1, ACT_RELU)
+        a = new(bs, N, 1, P, P)
+        c = new(bs, N, 1, P, P) if confidence else None
+        _lib.check(lib.omni_heads_f32(_p(x), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]),
+                                      ctypes.c_float(self.head_bias[1]), _p(a), _p(c), M, P, 1 if confidence else 0, self._s), "heads")
+        self.last = {"de_conv4_0": x, "layer4": layer4}
+        return a, c
+
+    def blend(self, a, c, erp_hw):
+        P = self.patch_size
+        if c is not None:
+            return pers2equi_conf(a, c, self.fov, self.nrows, P, erp_hw, layout=_lib.LAYOUT_BNCHW)
+        return pers2equi(a, self.fov, self.nrows, P, erp_hw, None, layout=_lib.LAYOUT_BNCHW)
+
+    def mlp_points(self, name, xyz, depth, Mo):
+        lib = _lib.load()
+        P4 = self.patch_size[0] // 4
+        out = torch.empty((Mo, P4, P4, 64), dtype=torch.float32, device=xyz.device)
+        s = ctypes.c_void_p(torch.cuda.current_stream(xyz.device).cuda_stream)
+        _lib.check(lib.omni_mlp_points_f32(_p(xyz), _p(depth), _p(self.w[name + ".w1"]), _p(self.w[name + ".b1"]),
+                                           _p(self.w[name + ".w2"]), _p(self.w[name + ".b2"]), _p(out), Mo, self.npatches,
+                                           P4 * P4, s), "mlp_points")
+        return out
+
+    def check_input(self, rgb):
+        if self.w is None:
+            raise RuntimeError("no weights loaded: call load_state_dict() first")
+        if not isinstance(rgb, torch.Tensor) or rgb.dim() != 4 or rgb.shape[1] != 3:
+            raise ValueError("expected an RGB panorama batch [B,3,H,W]")
+        if not rgb.is_cuda:
+            raise ValueError("the model runs on an MI355X only (got a CPU tensor); there is no CPU path")
+        if rgb.dtype != torch.float32:
+            raise ValueError("float32 input expected")
+        if rgb.device != self.device:
+            raise ValueError(f"weights are on {self.device}, input on {rgb.device}")
+        if _NPATCH[self.nrows] != self.npatches:
+            raise ValueError("npatches does not match nrows")

@@ -1,0 +1,74 @@
+"""spherical_fusion (single pass) — host-side mirror of /root/reference/model/spherical_model.py:190-314.
+
+Same class name, constructor arguments and forward signature as the reference:
+
+    net = spherical_fusion(nrows=4, npatches=18, patch_size=(128, 128), fov=(80, 80))
+    net.load_state_dict(ckpt)            # reference schema (5-D conv weights), 'module.' prefix optional
+    depth = net(rgb, confidence=True)    # rgb [B,3,H,W] float32 on the GPU -> [B,1,H,W]
+
+The forward is a launch sequence over libomnifusion_hip.so (see _engine.py); there is no autograd
+(inference only, as test.py:197 runs the reference under torch.no_grad()).  The object is a plain
+Python class, not an nn.Module: its parameters live in packed device buffers (BN folded, NHWC-GEMM
+layouts), and the reference's nn.DataParallel wrapping (test.py:107) has no counterpart here — one
+process per GPU shards the batch instead (bench.py).
+"""
+import torch
+
+from ._engine import Engine, strip_module_prefix
+from ..equi_pers.equi2pers_v3 import equi2pers_patches
+from .. import _lib
+from ..weights import schema
+
+
+class spherical_fusion:
+    _ITERATIVE = False
+
+    def __init__(self, nrows=4, npatches=18, patch_size=(128, 128), fov=(80, 80)):
+        self.nrows, self.npatches, self.patch_size, self.fov = nrows, npatches, patch_size, fov
+        self._eng = Engine(nrows, npatches, patch_size, fov, self._ITERATIVE)
+        self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.training = False
+
+    # ---- nn.Module-flavoured conveniences the reference scripts use
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if getattr(self, "_sd", None) is not None:
+            self._eng.pack(self._sd, self._device)
+        return self
+
+    def to(self, device):
+        return self.cuda(torch.device(device).index)
+
+    def state_dict_schema(self):
+        return schema(self.npatches, self._ITERATIVE)
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = strip_module_prefix(state_dict)
+        want = self.state_dict_schema()
+        missing = [k for k in want if k not in sd and not k.endswith("num_batches_tracked")]
+        if missing and strict:
+            raise RuntimeError(f"missing keys in state_dict: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        for k, (shape, _) in want.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shape)}")
+        self._sd = sd
+        if self._device is None:
+            raise RuntimeError("no MI355X visible: this model has no CPU path")
+        self._eng.pack(sd, self._device)
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    @torch.no_grad()
+    def forward(self, rgb, confidence=True):
+        e = self._eng
+        e.check_input(rgb)
+        bs, _, H, W = rgb.shape
+        with torch.cuda.device(rgb.device):
+            patches = equi2pers_patches(rgb, self.fov, self.nrows, self.patch_size, layout=_lib.LAYOUT_BNCHW)   # :243
+            a, c = e.network(patches, e.w["point_feat"], bs, confidence)                                        # :245-306
+            return e.blend(a, c, (H, W))                                                                        # :307-313

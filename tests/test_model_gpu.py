@@ -1,0 +1,184 @@
+"""GPU parity of the network operators and of the full models against (i) golden outputs of the
+reference itself (G6/G7: single pass and iterative, P=128) and (ii) the torch fp32 oracle.
+Gate: max |d| <= 1e-3 abs on depth (north_star)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import golden, smooth_erp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from omnifusion_amd import _lib as L
+    return L, L.load()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("cfg", [
+    # M, H, W, C1, C2, Cout, k, stride, pad, act, res
+    (3, 16, 16, 64, 0, 64, 3, 1, 1, 1, True),
+    (2, 17, 13, 32, 0, 32, 3, 1, 1, 1, False),
+    (5, 32, 32, 64, 0, 128, 3, 2, 1, 1, False),
+    (5, 32, 32, 64, 0, 128, 1, 2, 0, 0, False),
+    (4, 8, 8, 256, 256, 128, 3, 1, 1, 1, False),
+    (36, 4, 4, 512, 0, 512, 3, 1, 1, 1, True),
+    (18, 1, 1, 512, 0, 2048, 1, 1, 0, 2, False),
+    (40, 64, 64, 32, 0, 32, 3, 1, 1, 1, False),
+])
+def test_conv2d_vs_torch(cfg):
+    """omni_conv2d_nhwc_f32 against a plain PyTorch fp32 reference of the same op (CPU, float64 accumulate)."""
+    L, lib = _lib()
+    M, H, W, C1, C2, Cout, k, s, pad, act, use_res = cfg
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn(M, H, W, C1, generator=g)
+    x2 = torch.randn(M, H, W, C2, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, k, k, generator=g) / np.sqrt((C1 + C2) * k * k)
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    res = torch.randn(M, Ho, Wo, Cout, generator=g) if use_res else None
+    xin = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=s, padding=pad).permute(0, 2, 3, 1)
+    if use_res:
+        ref = ref + res.double()
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    d = lambda t: t.contiguous().to(DEV) if t is not None else None
+    X1, X2, WT, B, R = d(x1), d(x2), d(wt), d(b), d(res)
+    out = torch.empty((M, Ho, Wo, Cout), device=DEV)
+    rc = lib.omni_conv2d_nhwc_f32(_p(X1), _p(X2), _p(WT), _p(B), _p(R), _p(out), M, H, W, C1, C2, Cout, k, k, s, pad, act, _stream())
+    assert rc == 0, lib.omni_last_error()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_small_ops_vs_torch():
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(2)
+    # maxpool / upsample
+    x = torch.randn(3, 10, 12, 8, generator=g)
+    X = x.to(DEV)
+    mp = torch.empty((3, 5, 6, 8), device=DEV)
+    assert lib.omni_maxpool3x3s2_f32(_p(X), _p(mp), 3, 10, 12, 8, _stream()) == 0
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(mp.cpu(), ref)
+    for (Ho, Wo) in ((20, 24), (15, 30)):
+        up = torch.empty((3, Ho, Wo, 8), device=DEV)
+        assert lib.omni_upsample_bilinear_f32(_p(X), _p(up), 3, 10, 12, 8, Ho, Wo, _stream()) == 0
+        ref = F.interpolate(x.permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        assert (up.cpu() - ref).abs().max().item() < 1e-5
+    # layernorm
+    t = torch.randn(37, 512, generator=g) * 3 + 1
+    gw, gb = torch.randn(512, generator=g), torch.randn(512, generator=g)
+    y = torch.empty_like(t, device=DEV)
+    for eps in (1e-5, 1e-6):
+        assert lib.omni_layernorm512_f32(_p(t.to(DEV)), _p(gw.to(DEV)), _p(gb.to(DEV)), _p(y), 37, ctypes.c_float(eps), _stream()) == 0
+        assert (y.cpu() - F.layer_norm(t, (512,), gw, gb, eps)).abs().max().item() < 2e-5
+    # attention (blocks.py:52-62)
+    for (B, N) in ((2, 18), (1, 46)):
+        q = torch.randn(B * N, 512, generator=g); kv = torch.randn(B * N, 1024, generator=g)
+        o = torch.empty((B * N, 512), device=DEV)
+        assert lib.omni_attention_f32(_p(q.to(DEV)), _p(kv.to(DEV)), _p(o), B, N, _stream()) == 0
+        qh = q.reshape(B, N, 4, 128).permute(0, 2, 1, 3)
+        kvh = kv.reshape(B, N, 2, 4, 128).permute(2, 0, 3, 1, 4)
+        att = ((qh @ kvh[0].transpose(-2, -1)) * 128 ** -0.5).softmax(-1)
+        ref = (att @ kvh[1]).transpose(1, 2).reshape(B * N, 512)
+        assert (o.cpu() - ref).abs().max().item() < 2e-5
+
+
+def _nets():
+    from omnifusion_amd.model.spherical_model import spherical_fusion
+    from omnifusion_amd.model.spherical_model_iterative import spherical_fusion as spherical_fusion_it
+    from omnifusion_amd.weights import make_state_dict
+    return spherical_fusion, spherical_fusion_it, make_state_dict
+
+
+def test_single_pass_model_golden():
+    """G6: the reference's own output (P=128, 64x128 ERP, B=2), confidence True and False."""
+    spherical_fusion, _, make_state_dict = _nets()
+    g = golden("G6_model_single")
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict({"module." + k: v for k, v in make_state_dict(42, 18, False).items()})   # DataParallel-style keys
+    rgb = torch.from_numpy(g["rgb"]).to(DEV)
+    out = net(rgb, confidence=True)
+    assert out.shape == (2, 1, 64, 128) and out.dtype == torch.float32
+    d = np.abs(out.cpu().numpy() - g["depth_conf"]).max()
+    assert d <= 1e-3, f"confidence=True: max |d| = {d}"
+    # intermediate check-points: last decoder feature map (sub-sampled)
+    x = net._eng.last["de_conv4_0"].reshape(2, 18, 128, 128, 32).permute(0, 4, 2, 3, 1)[:, :, ::8, ::8, :]
+    assert np.abs(x.cpu().numpy() - g["de_conv4_0_sub"]).max() <= 1e-3
+    out2 = net(rgb, confidence=False)
+    d = np.abs(out2.cpu().numpy() - g["depth_noconf"]).max()
+    assert d <= 1e-3, f"confidence=False: max |d| = {d}"
+    # batch independence: image 1 alone gives the same bits as inside the batch (shard equivalence, SURVEY 4 iv)
+    assert torch.equal(net(rgb[1:2], confidence=True), out[1:2])
+
+
+def test_iterative_model_golden():
+    _, spherical_fusion_it, make_state_dict = _nets()
+    g = golden("G7_model_iterative")
+    net = spherical_fusion_it(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, True))
+    rgb = torch.from_numpy(g["rgb"]).to(DEV)
+    o = net(rgb, iter=2)                               # confidence=False default, as test.py:198 calls it
+    assert isinstance(o, list) and len(o) == 2
+    assert np.abs(o[0].cpu().numpy() - g["it0"]).max() <= 1e-3
+    assert np.abs(o[1].cpu().numpy() - g["it1"]).max() <= 1e-3
+    o = net(rgb, 2, confidence=True)
+    assert np.abs(o[0].cpu().numpy() - g["it0_conf"]).max() <= 1e-3
+    assert np.abs(o[1].cpu().numpy() - g["it1_conf"]).max() <= 1e-3
+
+
+def test_model_config1_size():
+    """BASELINE config 1/2 shape: 512x1024 ERP, nrows=4, P=128 (the only size the network exists at), smooth
+    synthetic panorama, against (i) the reference's own output (G6b) and (ii) the torch fp32 oracle.
+    At this ERP size ANY two fp32 evaluations of the geometry differ at isolated pixels (the reference vs the CPU
+    oracle: 1 pixel of 524288 above 1e-3, max 3.8e-3, p99.99 = 7.7e-5), so the gate is the outlier-bounded one of
+    SURVEY 8d: |d| <= 1e-3 for >= 99.999 % of the pixels, |d| <= 2e-2 everywhere."""
+    spherical_fusion, _, make_state_dict = _nets()
+    from oracle import model_ref
+    from _util import assert_close_outliers
+    sd = make_state_dict(42, 18, False)
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(sd)
+    rgb = torch.from_numpy(smooth_erp(77, 1, 3, 512, 1024))
+    out = net(rgb.to(DEV), confidence=True).cpu().numpy()
+    g = golden("G6b_model_single_512x1024")
+    assert_close_outliers(out[:, :, ::2, ::2], g["depth_conf_sub"], tol=1e-3, max_tol=2e-2, frac=1e-5, what="vs reference")
+    ref = model_ref.spherical_fusion_forward(sd, rgb, confidence=True).numpy()
+    assert_close_outliers(out, ref, tol=1e-3, max_tol=2e-2, frac=1e-5, what="vs oracle")
+    assert np.quantile(np.abs(out - ref), 0.9999) < 2e-4
+
+
+def test_model_errors():
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 128, device=DEV))                      # no weights yet
+    sd = make_state_dict(42, 18, False)
+    bad = dict(sd); bad.pop("layer3.2.conv1.weight")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad)
+    net.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 64, 128))                                   # CPU tensor
+    # the reference cannot run P=256 (finding 0.1): same failure class here, not a silent wrong answer
+    net256 = spherical_fusion_it(4, 18, (256, 256), (80, 80)).cuda()
+    net256.load_state_dict(make_state_dict(42, 18, True))
+    with pytest.raises(RuntimeError):
+        net256(torch.zeros(1, 3, 64, 128, device=DEV), 1)

@@ -1,0 +1,60 @@
+"""CPU: the torch fp32 model oracle (oracle/model_ref.py) against golden outputs of the reference
+itself (G6 single pass, G7 iterative), and the state_dict schema against the reference's listing."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from _util import golden, GOLDEN
+from oracle import model_ref as mr
+from omnifusion_amd.weights import make_state_dict, schema
+
+
+def test_state_dict_schema_matches_reference():
+    for it, name in ((False, "single"), (True, "iterative")):
+        ref = json.load(open(os.path.join(GOLDEN, f"state_dict_schema_{name}.json")))
+        s = schema(18, it)
+        assert list(s) == list(ref)
+        for k in s:
+            assert list(s[k][0]) == ref[k][0] and "torch." + s[k][1] == ref[k][1], k
+    assert len(schema(18, False)) == 363 and len(schema(18, True)) == 375
+
+
+def test_weights_are_deterministic():
+    a, b = make_state_dict(42, 18, False), make_state_dict(42, 18, False)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = make_state_dict(43, 18, False)
+    assert not torch.equal(a["conv1.weight"], c["conv1.weight"])
+
+
+def test_single_pass_oracle_golden():
+    g = golden("G6_model_single")
+    sd = make_state_dict(42, 18, False)
+    taps = {}
+    out = mr.spherical_fusion_forward(sd, torch.from_numpy(g["rgb"]), confidence=True, taps=taps)
+    assert np.abs(out.numpy() - g["depth_conf"]).max() < 2e-4
+    out = mr.spherical_fusion_forward(sd, torch.from_numpy(g["rgb"]), confidence=False)
+    assert np.abs(out.numpy() - g["depth_noconf"]).max() < 2e-4
+    pred = taps["pred"].reshape(2, 18, 1, 128, 128).permute(0, 2, 3, 4, 1).numpy()[:, :, ::4, ::4, :]
+    assert np.abs(pred - g["pred_sub"]).max() < 2e-4
+    assert g["depth_conf"].min() > 0.1 and g["depth_conf"].max() < 10.0       # the synthetic net yields depth-like values
+
+
+def test_iterative_oracle_golden():
+    g = golden("G7_model_iterative")
+    sd = make_state_dict(42, 18, True)
+    o = mr.spherical_fusion_iterative_forward(sd, torch.from_numpy(g["rgb"]), 2, confidence=False)
+    assert np.abs(o[0].numpy() - g["it0"]).max() < 2e-4 and np.abs(o[1].numpy() - g["it1"]).max() < 2e-4
+    o = mr.spherical_fusion_iterative_forward(sd, torch.from_numpy(g["rgb"]), 2, confidence=True)
+    assert np.abs(o[0].numpy() - g["it0_conf"]).max() < 2e-4 and np.abs(o[1].numpy() - g["it1_conf"]).max() < 2e-4
+
+
+def test_single_pass_oracle_config1_size():
+    """512x1024 ERP (BASELINE config 1), P=128: oracle vs the reference's own output (G6b), outlier-bounded
+    gate (see tests/test_model_gpu.py::test_model_config1_size for why max-norm cannot hold at this size)."""
+    from _util import smooth_erp, assert_close_outliers
+    g = golden("G6b_model_single_512x1024")
+    sd = make_state_dict(42, 18, False)
+    out = mr.spherical_fusion_forward(sd, torch.from_numpy(smooth_erp(77, 1, 3, 512, 1024)), confidence=True).numpy()
+    assert_close_outliers(out[:, :, ::2, ::2], g["depth_conf_sub"], tol=1e-3, max_tol=2e-2, frac=1e-5)

@@ -4,10 +4,20 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A "step" is one pass of the hot path over one per-GPU batch of synthetic
-panoramas that are already resident in HBM.  Panoramas shard by image (no data-path collective,
-SURVEY.md §8e), so scaling is weak: every rank processes `--batch` panoramas per step.
-Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md §Measurement).
+One process per GPU.  A "step" is one full forward of the single-pass spherical_fusion model
+(equi2pers -> ResNet-34 U-Net + transformer over the B*18 patches -> confidence pers2equi) over one
+per-GPU batch of synthetic panoramas already resident in HBM.  Panoramas shard by image (no
+data-path collective), so scaling is weak: every rank processes `--batch` panoramas
+per step and `value` = all panoramas of all ranks / max-over-ranks time.
+
+Workload notes (DESIGN.md "Measurement"):
+  * the reference network only exists at patch size 128 (SURVEY.md finding 0.1: its token width is
+    32*(P/32)^2 = 512 only for P = 128; P = 256 raises in the reference), so panoramas/s is measured
+    at 512x1024 ERP, nrows = 4 (18 patches), P = 128;
+  * the resample pair named by the metric (18 x 256^2 patches, equi2pers C=3 + pers2equi C=1) is
+    timed in the same run and reported as `roofline_resample` (HBM-bound);
+  * `roofline` is the dominant part of the step: the conv/GEMM network on the fp32 matrix cores.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -21,43 +31,44 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3-6.9 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector peak)
 ERP_H, ERP_W, NROWS, NPATCH, FOV = 512, 1024, 4, 18, (80.0, 80.0)
+NET_GFLOP_PER_PANO = 71.3      # 2 x 35.66 GMAC at P=128, N=18 (probed with forward hooks)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="panoramas per GPU per step (8 = BASELINE cfg 4 shard)")
-    ap.add_argument("--patch", type=int, default=256, help="resample patch size (BASELINE: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(patch):
-    """The C oracle ('port' of the reference algorithm) timed on this host's cores on a
-    bounded sample: ONE panorama through equi2pers (C=3) + pers2equi (C=1)."""
-    from oracle import c_oracle as co
+def cpu_baseline():
+    """The CPU oracle ('port' of the reference forward: oracle/model_ref.py on torch-CPU fp32 + the C
+    restatement of equi2pers/pers2equi) timed on this host's cores on a bounded sample."""
+    from oracle import c_oracle as co, model_ref
+    from omnifusion_amd.weights import make_state_dict
     co.build()
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    rng = np.random.default_rng(0)
-    erp = rng.random((1, 3, ERP_H, ERP_W), dtype=np.float32)
-    pin = rng.random((1, 1, patch, patch, NPATCH), dtype=np.float32)
-    co.equi2pers(erp[:, :, :64, :128], FOV, NROWS, (16, 16))           # load + warm
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sd = make_state_dict(42, NPATCH, False)
+    rgb = torch.rand((1, 3, ERP_H, ERP_W), generator=torch.Generator().manual_seed(0))
+    model_ref.spherical_fusion_forward(sd, rgb[:, :, :64, :128], NROWS, 128, FOV, True)          # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        co.equi2pers(erp, FOV, NROWS, (patch, patch))
-        co.pers2equi(pin, FOV, NROWS, (patch, patch), (ERP_H, ERP_W))
+        model_ref.spherical_fusion_forward(sd, rgb, NROWS, 128, FOV, True)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or n >= 20:
+        if dt > 12.0 or n >= 8:
             break
-    return {"value": n / dt, "unit": "panoramas/s", "cores": cores, "kind": "port",
-            "sample": f"{n} panorama(s) 512x1024 -> 18x{patch}^2 (equi2pers C=3 + pers2equi C=1), "
-                      f"C oracle with OpenMP over {cores} threads"}
+    return {"value": n / dt, "unit": "panoramas/s", "cores": threads, "kind": "port",
+            "sample": f"{n} panorama(s) 512x1024, single-pass model P=128 confidence=True, torch-CPU fp32 oracle "
+                      f"({threads} threads) + C/OpenMP equi2pers/pers2equi"}
 
 
 def main():
@@ -76,18 +87,17 @@ def main():
     from omnifusion_amd import _lib
     from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
     from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi
+    from omnifusion_amd.model.spherical_model import spherical_fusion
+    from omnifusion_amd.weights import make_state_dict
     _lib.load()
 
-    B, P = args.batch, args.patch
+    B = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    erp = torch.rand((B, 3, ERP_H, ERP_W), generator=g).to(dev)               # synthetic RGB panoramas
-    depth_patches = torch.rand((B, NPATCH, 1, P, P), generator=g).to(dev)     # synthetic per-patch depth
+    rgb = torch.rand((B, 3, ERP_H, ERP_W), generator=g).to(dev)               # synthetic RGB panoramas (BGR/255-like range)
+    net = spherical_fusion(NROWS, NPATCH, (128, 128), FOV).cuda(local)
+    net.load_state_dict(make_state_dict(42, NPATCH, False))                   # random-init weights of the reference architecture
+    eng = net._eng
     LAY = _lib.LAYOUT_BNCHW
-
-    def step():
-        p = equi2pers_patches(erp, FOV, NROWS, (P, P), layout=LAY)
-        e = pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
-        return p, e
 
     def barrier():
         if world > 1:
@@ -95,47 +105,74 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        net(rgb, confidence=True)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(args.steps):                                               # = spherical_fusion.forward, stage by stage
         ev[k][0].record()
-        p = equi2pers_patches(erp, FOV, NROWS, (P, P), layout=LAY)
+        patches = equi2pers_patches(rgb, FOV, NROWS, (128, 128), layout=LAY)
         ev[k][1].record()
-        e = pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
+        a, c = eng.network(patches, eng.w["point_feat"], B, True)
         ev[k][2].record()
+        depth = eng.blend(a, c, (ERP_H, ERP_W))
+        ev[k][3].record()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    assert depth.shape == (B, 1, ERP_H, ERP_W) and bool(torch.isfinite(depth).all())
+    sec = lambda i: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) * 1e-3
+    t_e2p, t_net, t_p2e = sec(0), sec(1), sec(2)
+    tflops = NET_GFLOP_PER_PANO * B / t_net / 1e3
 
-    t_e2p = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)])) * 1e-3
-    t_p2e = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)])) * 1e-3
-    s = 4
-    bytes_e2p = B * 3 * (ERP_H * ERP_W + P * P * NPATCH) * s          # SURVEY §8d algorithmic bytes
-    bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * s
-    gbs_pair = (bytes_e2p + bytes_p2e) / (t_e2p + t_p2e) / 1e9
+    # ---- the resample pair at the metric's patch size (18 x 256^2), same run, HIP events on the launch stream
+    P = 256
+    depth_patches = torch.rand((B, NPATCH, 1, P, P), generator=g).to(dev)
+    K = max(args.steps, 20)
+    for _ in range(3):
+        equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY); pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
+    er = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    torch.cuda.synchronize()
+    for k in range(K):
+        er[k][0].record()
+        equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY)
+        er[k][1].record()
+        pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
+        er[k][2].record()
+    torch.cuda.synchronize()
+    r_e2p = float(np.mean([er[k][0].elapsed_time(er[k][1]) for k in range(K)])) * 1e-3
+    r_p2e = float(np.mean([er[k][1].elapsed_time(er[k][2]) for k in range(K)])) * 1e-3
+    bytes_e2p = B * 3 * (ERP_H * ERP_W + P * P * NPATCH) * 4          # SURVEY 8d algorithmic bytes
+    bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * 4
+    gbs_pair = (bytes_e2p + bytes_p2e) / (r_e2p + r_p2e) / 1e9
+
     out = {
         "metric": "panoramas/sec at 512x1024 ERP, N=18 256^2 patches; equi2pers+pers2equi GB/s vs HBM peak",
         "value": world * B * args.steps / dt, "unit": "panoramas/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"resample pair only (network not in this step yet): {B} panoramas/GPU/step, "
-                               f"512x1024 ERP fov 80 nrows 4 -> 18x{P}^2 patches (equi2pers C=3) and back "
-                               f"(pers2equi C=1), patch-major layout, inputs resident in HBM",
+        "config": {"workload": f"cfg2/cfg4 shard: {B} panoramas/GPU/step, 512x1024 ERP, fov 80, nrows 4 (18 patches); full "
+                               "single-pass spherical_fusion forward (confidence=True) at patch size 128 — the only size the "
+                               "reference network exists at (SURVEY 0.1); random-init weights (seed 42); inputs resident in HBM; "
+                               "resample pair at 18x256^2 reported in roofline_resample",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}"},
-        "roofline": {"bound": "hbm", "kernel": "e2p_planar_kernel<float,4> + p2e_kernel<float,8,false>",
-                     "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
-                     "traffic": None,
-                     "equi2pers": {"us": t_e2p * 1e6, "bytes": bytes_e2p, "GB/s": bytes_e2p / t_e2p / 1e9},
-                     "pers2equi": {"us": t_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / t_p2e / 1e9}},
+        "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3},
+        "roofline": {"bound": "mfma", "kernel": "network section (conv_igemm_f32_kernel<...> dominant; includes stem/pool/"
+                                                "upsample/LN/attention/heads launches)",
+                     "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9},
+        "roofline_resample": {"bound": "hbm", "kernel": "e2p_lds_kernel + p2e_kernel<float,8,false,true> at 18x256^2, B=%d" % B,
+                              "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
+                              "traffic": None,
+                              "equi2pers": {"us": r_e2p * 1e6, "bytes": bytes_e2p, "GB/s": bytes_e2p / r_e2p / 1e9},
+                              "pers2equi": {"us": r_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / r_p2e / 1e9}},
     }
     if rank == 0:
-        out["cpu_baseline"] = None if args.no_cpu_baseline or world > 1 else cpu_baseline(P)
+        out["cpu_baseline"] = None if args.no_cpu_baseline or world > 1 else cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,0 +1,78 @@
+"""CPU: the C-ABI boundary — every symbol include/omnifusion.h declares is exported by the built
+library and bound by the loader; the product never imports the oracle; the package fails loudly
+without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "omnifusion.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from omnifusion_amd import _lib, build
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH) if False else None      # loading needs torch's HIP runtime first: go through _lib
+    L = _lib.load()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/omnifusion.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ set(declared)
+    assert L.omni_version() == 100
+    assert [L.omni_num_patches(n) for n in (3, 4, 5, 6, 7)] == [10, 18, 26, 46, -1]
+    cp = (ctypes.c_float * 36)()
+    assert L.omni_patch_centers(4, 0, cp) == 0 and abs(cp[0] + 2 / 3) < 1e-6 and cp[1] == -0.75
+    assert L.omni_patch_centers(9, 0, cp) == _lib.OMNI_ERR_INVALID
+    assert b"nrows" in L.omni_last_error()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under omnifusion_amd/ (or bench.py outside its cpu_baseline leg)
+    may import, link or call it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle|libomni_oracle|oracle[/.]c_oracle|oracle[/.]model_ref\b(?!\.py)", re.M)
+    for dp, _, files in os.walk(os.path.join(ROOT, "omnifusion_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not pat.search(txt), f"{os.path.join(dp, f)} uses the oracle"
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    body = bench.split("def cpu_baseline")[1].split("\ndef main")[0]
+    assert "from oracle" in body
+    assert "oracle" not in bench.split("\ndef main")[1].replace("cpu_baseline", "")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_cpu_fallback():
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers
+    from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi
+    from omnifusion_amd.model.spherical_model import spherical_fusion
+    with pytest.raises(ValueError, match="no CPU path"):
+        equi2pers(torch.zeros(1, 3, 8, 16), 80, 4, 8)
+    with pytest.raises(ValueError, match="no CPU path"):
+        pers2equi(torch.zeros(1, 1, 8, 8, 18), 80, 4, 8, (16, 32), "x")
+    with pytest.raises(ValueError):
+        equi2pers(torch.zeros(1, 3, 8, 16), 80, 7, 8)
+    net = spherical_fusion()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        from omnifusion_amd.weights import make_state_dict
+        net.load_state_dict(make_state_dict(1, 18, False))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import omnifusion_amd._lib as L\n"
+            "L.LIB_PATH = %r\n"
+            "try:\n    L.load()\nexcept ImportError as e:\n    print('RAISED', type(e).__name__)\n") % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED OmniLibraryMissing" in out.stdout, out.stdout + out.stderr

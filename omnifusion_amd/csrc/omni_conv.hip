@@ -37,6 +37,8 @@ struct ConvArgs {
     int M, H, W, C1, C2, Ho, Wo, Cout;
     int KH, KW, stride, pad, act;
     int rows;                                // M*Ho*Wo
+    int splitk;                              // >1: blockIdx.y owns a K range and writes raw partial sums to ws[y]
+    float* ws;                               // [splitk][rows][Cout]
 };
 
 constexpr int BK = 32;
@@ -110,12 +112,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvArgs a)
     const float* Aw = As + (wm * TM * 32 + frow) * LDP + fk;
     const float* Bw = Bs + (wn * TN * 32 + frow) * LDP + fk;
 
-    fetch(0);
-    for (int ks = 0; ks < ksteps; ++ks) {
+    int ks_begin = 0, ks_end = ksteps;
+    if (a.splitk > 1) {
+        const int per = (ksteps + a.splitk - 1) / a.splitk;
+        ks_begin = blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
+    }
+    if (ks_begin < ks_end) fetch(ks_begin);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
         __syncthreads();                     // previous step's fragment reads are done
         stash();
         __syncthreads();
-        if (ks + 1 < ksteps) fetch(ks + 1);  // next tiles in flight while the matrix cores work
+        if (ks + 1 < ks_end) fetch(ks + 1);  // next tiles in flight while the matrix cores work
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             f4v fa[TM], fb[TN];
@@ -143,7 +150,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvArgs a)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int r = row0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (r < a.rows) {
+                if (r < a.rows && a.splitk > 1) {
+                    a.ws[((size_t)blockIdx.y * a.rows + r) * a.Cout + col] = acc[i][j][reg];
+                } else if (r < a.rows) {
                     float v = acc[i][j][reg] + bj;
                     const size_t o = (size_t)r * a.Cout + col;
                     if (a.res) v += a.res[o];
@@ -160,16 +169,60 @@ template <int BM, int BN, int WM, int WN>
 void launch_cfg(const ConvArgs& a, hipStream_t s)
 {
     const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+}
+
+// dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, float* __restrict__ dst,
+                                                            size_t n4, int Cout, int splitk, size_t slab, int act)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t o = i * 4;
+    f4v v = *reinterpret_cast<const f4v*>(ws + o);
+    for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f4v*>(ws + (size_t)s * slab + o);
+    if (bias) v += *reinterpret_cast<const f4v*>(bias + (o % Cout));
+    if (res) v += *reinterpret_cast<const f4v*>(res + o);
+    if (act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (act == OMNI_ACT_GELU) {
+        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f)); v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
+        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+    }
+    *reinterpret_cast<f4v*>(dst + o) = v;
+}
+
+// split factor for a problem: aim at >= 512 blocks when the plain launch leaves most of the 256 CUs idle
+int plan_splitk(long long rows, int Cout, int ksteps)
+{
+    long long blocks;
+    if (Cout % 64 != 0) blocks = ((rows + 127) / 128) * (Cout / 32);
+    else {
+        const long long b128 = ((rows + 127) / 128) * (Cout / 64);
+        blocks = b128 >= 512 ? b128 : ((rows + 63) / 64) * (Cout / 64);
+    }
+    if (blocks >= 384 || ksteps < 8) return 1;
+    long long s = (640 + blocks - 1) / blocks;
+    if (s > ksteps / 4) s = ksteps / 4;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
 }
 }  // namespace
 
+// Split factor the library would pick for `rows` output pixels.  Callers that need results that do not depend on the
+// batch size bit-for-bit (image-sharded multi-GPU runs) plan with a NOMINAL row count and pass the factor explicitly.
+extern "C" int omni_conv2d_splitk_plan(long long rows, int Cout, int ksteps) { return plan_splitk(rows, Cout, ksteps); }
+
 // out[M,Ho,Wo,Cout] = act(conv(src1 ++ src2, wt) + bias + res).  wt is [Cout][KH*KW*(C1+C2)] with k ordered
 // (ky, kx, c).  Requirements: C1 % 32 == 0, C2 % 32 == 0, Cout % 32 == 0.  A plain GEMM is the case
-// H = W = KH = KW = 1 (rows = M).
-extern "C" int omni_conv2d_nhwc_f32(const float* src1, const float* src2, const float* wt, const float* bias,
-                                    const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
-                                    int KH, int KW, int stride, int pad, int act, omni_stream_t stream)
+// H = W = KH = KW = 1 (rows = M).  With a workspace of omni_conv2d_ws_bytes(...) bytes, problems that would occupy
+// only a fraction of the 256 CUs (layer4, the decoder's first stage, every transformer GEMM at M = B*N rows) are
+// split along K over blockIdx.y (`splitk` ranges, workspace ws of splitk*rows*Cout floats) and summed by a second,
+// deterministic pass.  splitk <= 1: plain launch.
+extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, const float* wt, const float* bias,
+                                       const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                                       int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                       omni_stream_t stream)
 {
     if (!src1 || !wt || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: null pointer");
     if (C1 <= 0 || C1 % BK || C2 < 0 || C2 % BK || Cout <= 0 || Cout % 32 || (C2 > 0 && !src2))
@@ -186,11 +239,30 @@ extern "C" int omni_conv2d_nhwc_f32(const float* src1, const float* src2, const 
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv2d: too many pixels for 32-bit row indices");
     a.rows = (int)rows;
     hipStream_t s = (hipStream_t)stream;
+    int S = splitk;
+    if (S > KH * KW * ((C1 + C2) / BK)) S = KH * KW * ((C1 + C2) / BK);
+    if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
+        OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: split-K workspace too small");
+    a.splitk = S; a.ws = ws;
     // tile choice: 128-row tiles when they alone fill the 256 CUs twice over, 64-row tiles otherwise
     const long long blocks128 = ((rows + 127) / 128) * (Cout / 64);
     if (Cout % 64 != 0)        launch_cfg<128, 32, 4, 1>(a, s);
     else if (blocks128 >= 512) launch_cfg<128, 64, 4, 1>(a, s);
     else                       launch_cfg<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
+    if (S > 1) {
+        const size_t n4 = (size_t)rows * Cout / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, bias, res, dst,
+                           n4, Cout, S, (size_t)rows * Cout, act);
+        OMNI_HIP(hipGetLastError());
+    }
     return OMNI_OK;
+}
+
+extern "C" int omni_conv2d_nhwc_f32(const float* src1, const float* src2, const float* wt, const float* bias,
+                                    const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                                    int KH, int KW, int stride, int pad, int act, omni_stream_t stream)
+{
+    return omni_conv2d_nhwc_f32_ws(src1, src2, wt, bias, res, dst, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act,
+                                   1, nullptr, 0, stream);
 }

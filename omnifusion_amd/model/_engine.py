@@ -116,16 +116,42 @@ class Engine:
         Ho = (H + 2 * pad - k) // stride + 1
         Wo = (Wd + 2 * pad - k) // stride + 1
         out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-        rc = lib.omni_conv2d_nhwc_f32(_p(x), _p(x2), _p(self.w[key + ".w"]), _p(self.w[key + ".b"]) if bias else None,
-                                      _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, self._s)
+        S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
+        rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), _p(self.w[key + ".b"]) if bias else None,
+                                         _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws),
+                                         ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "conv2d " + key)
         return out
+
+    NOMINAL_BATCH = 8
+
+    def _splitk(self, rows, Cout, ksteps, device):
+        """Split factor planned for a NOMINAL batch (not the actual one), so that the K summation order — and with it
+        every output bit — is the same whether a panorama is processed alone or inside a batch (image-sharded
+        multi-GPU runs must reproduce single-GPU results bit for bit)."""
+        rows_nominal = rows // self._bs * self.NOMINAL_BATCH
+        S = int(_lib.load().omni_conv2d_splitk_plan(ctypes.c_longlong(rows_nominal), Cout, ksteps))
+        if S <= 1:
+            return 1, None, 0
+        ws, nb = self._workspace(S * rows * Cout * 4, device)
+        return S, ws, nb
+
+    def _workspace(self, nbytes, device):
+        """split-K scratch: one buffer reused by every launch of the stream (launches are stream-ordered)"""
+        nbytes = int(nbytes)
+        if nbytes == 0:
+            return None, 0
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() * 4 < nbytes or ws.device != device:
+            self._ws = ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        return ws, ws.numel() * 4
 
     def _gemm(self, x, wkey, bkey, rows, K, Nout, act=ACT_NONE, res=None):
         lib = _lib.load()
         out = torch.empty((rows, Nout), dtype=torch.float32, device=x.device)
-        rc = lib.omni_conv2d_nhwc_f32(_p(x), None, _p(self.w[wkey]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
-                                      rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, self._s)
+        S, ws, nb = self._splitk(rows, Nout, K // 32, x.device)
+        rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), None, _p(self.w[wkey]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
+                                         rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "gemm " + wkey)
         return out
 
@@ -148,6 +174,7 @@ class Engine:
         self._s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         N, P = self.npatches, self.patch_size[0]
         M = bs * N
+        self._bs = bs
         P2, P4, P8, P16, P32 = P // 2, P // 4, P // 8, P // 16, P // 32
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         conv1 = new(M, P2, P2, 64)

@@ -28,6 +28,14 @@ namespace {
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+// raw buffer descriptor (V#) over [p, p+bytes): stride 0, num_records = bytes; gfx9-family flags dword
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
+                                             (int)(unsigned)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+
 struct ConvArgs {
     const float* src1; const float* src2;   // NHWC inputs (src2 may be null)
     const float* wt;                         // [Cout][KH*KW*(C1+C2)], BN folded
@@ -63,37 +71,57 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvArgs a)
     const int ksteps = a.KH * a.KW * cchunks;
     const int Kfull = a.KH * a.KW * Cin;
 
-    // ---- loader geometry: thread -> (row lr + 32*i, k quad kq)
+    // ---- loader geometry: thread -> (row lr + 32*i, k quad kq).  All addressing is 32-bit: raw buffer loads (SGPR
+    // descriptor + VGPR byte offset); a tap outside the image gets an out-of-range offset, for which the buffer unit
+    // returns zeros (the conv's zero padding) without a branch; per load the VALU cost is a bit test, an add, a select.
     const int lr = t >> 3, kq = (t & 7) * 4;
-    int pm[APASS], poy[APASS], pox[APASS];
+    int pix[APASS];                                              // pixel index of the (virtual, possibly padded) window origin
+    unsigned vmask[APASS];                                       // bit (ky*KW+kx): tap inside the image
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
         const int r = row0 + lr + 32 * i;
+        vmask[i] = 0; pix[i] = 0;
         if (r < a.rows) {
             const int hw = a.Ho * a.Wo;
             const int m = r / hw, rem = r - m * hw;
-            pm[i] = m; poy[i] = (rem / a.Wo) * a.stride - a.pad; pox[i] = (rem % a.Wo) * a.stride - a.pad;
-        } else { pm[i] = -1; poy[i] = 0; pox[i] = 0; }
-    }
-    const float* wrow[BPASS];
+            const int oy = (rem / a.Wo) * a.stride - a.pad, ox = (rem % a.Wo) * a.stride - a.pad;
+            pix[i] = (m * a.H + oy) * a.W + ox;
+            unsigned vm = 0;
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) wrow[i] = a.wt + (size_t)(col0 + lr + 32 * i) * Kfull + kq;
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    if (ky < a.KH && kx < a.KW && (unsigned)(oy + ky) < (unsigned)a.H && (unsigned)(ox + kx) < (unsigned)a.W)
+                        vm |= 1u << (ky * a.KW + kx);
+            vmask[i] = vm;
+        }
+    }
+    const rsrc_t rs1 = make_rsrc(a.src1, (size_t)a.M * a.H * a.W * a.C1 * 4);
+    const rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? (size_t)a.M * a.H * a.W * a.C2 * 4 : 0);
+    const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * Kfull * 4);
+    int wbase[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) wbase[i] = ((col0 + lr + 32 * i) * Kfull + kq) * 4;
 
     f4v ra[APASS], rb[BPASS];
+    int f_tap = 0, f_c = 0, f_ky = 0, f_kx = 0;                  // (tap, channel chunk) of the NEXT fetch
+    auto seek = [&](int ks) { f_tap = ks / cchunks; f_c = (ks - f_tap * cchunks) * BK; f_ky = f_tap / a.KW; f_kx = f_tap - f_ky * a.KW; };
     auto fetch = [&](int ks) {
-        const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * BK;
-        const int ky = tap / a.KW, kx = tap - ky * a.KW;
-        const float* src; int cs, cc;
-        if (c0 < a.C1) { src = a.src1; cs = a.C1; cc = c0; } else { src = a.src2; cs = a.C2; cc = c0 - a.C1; }
+        const bool first = f_c < a.C1;
+        const int cs = first ? a.C1 : a.C2;                                        // scalar selects: no per-lane arrays
+        const int soff = ((f_ky * a.W + f_kx) * cs + (first ? f_c : f_c - a.C1) + kq) * 4;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            const int iy = poy[i] + ky, ix = pox[i] + kx;
-            const bool ok = (pm[i] >= 0) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
-            ra[i] = (f4v)(0.0f);
-            if (ok) ra[i] = *reinterpret_cast<const f4v*>(src + ((size_t)(pm[i] * a.H + iy) * a.W + ix) * cs + cc + kq);
+            // (the range check of a raw buffer load sees the VGPR offset only, and the origin of a padded window may
+            //  lie before the tensor: the tap term is folded into the VGPR offset)
+            const int off = ((vmask[i] >> f_tap) & 1u) ? pix[i] * cs * 4 + soff : (int)0x80000000;
+            ra[i] = first ? __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0))
+                          : __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs2, off, 0, 0));
         }
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) rb[i] = *reinterpret_cast<const f4v*>(wrow[i] + (size_t)ks * BK);
+        for (int i = 0; i < BPASS; ++i) rb[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, wbase[i], ks * (BK * 4), 0));
+        f_c += BK;
+        if (f_c == Cin) { f_c = 0; ++f_tap; if (++f_kx == a.KW) { f_kx = 0; ++f_ky; } }
     };
     auto stash = [&]() {
 #pragma unroll
@@ -117,6 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvArgs a)
         const int per = (ksteps + a.splitk - 1) / a.splitk;
         ks_begin = blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
     }
+    seek(ks_begin);
     if (ks_begin < ks_end) fetch(ks_begin);
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         __syncthreads();                     // previous step's fragment reads are done
@@ -227,8 +256,8 @@ extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, con
     if (!src1 || !wt || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: null pointer");
     if (C1 <= 0 || C1 % BK || C2 < 0 || C2 % BK || Cout <= 0 || Cout % 32 || (C2 > 0 && !src2))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: channels must be multiples of 32");
-    if (M <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
-        OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: bad shape");
+    if (M <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || KH > 3 || KW > 3 || stride <= 0 || pad < 0)
+        OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: bad shape (kernels up to 3x3)");
     ConvArgs a;
     a.src1 = src1; a.src2 = src2; a.wt = wt; a.bias = bias; a.res = res; a.dst = dst;
     a.M = M; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout;
@@ -238,6 +267,8 @@ extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, con
     if (rows <= 0 || rows >= (1ll << 31) || (long long)M * H * W >= (1ll << 31))
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv2d: too many pixels for 32-bit row indices");
     a.rows = (int)rows;
+    if ((long long)M * H * W * (C1 > C2 ? C1 : C2) * 4 >= (1ll << 31) || (long long)Cout * KH * KW * (C1 + C2) * 4 >= (1ll << 31))
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv2d: an operand of 2 GiB or more (32-bit buffer offsets)");
     hipStream_t s = (hipStream_t)stream;
     int S = splitk;
     if (S > KH * KW * ((C1 + C2) / BK)) S = KH * KW * ((C1 + C2) / BK);

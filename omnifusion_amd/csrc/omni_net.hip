@@ -213,38 +213,50 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
-// heads: x [M,P,P,32] -> a = relu(conv_pred(x)) * (conf ? sigmoid(conv_w(x)) : 1), c = sigmoid(conv_w(x)); planar [M,P,P]
+// heads: x [M,P,P,32] -> a = relu(conv_pred(x)) * (conf ? sigmoid(conv_w(x)) : 1), c = sigmoid(conv_w(x)); planar [M,P,P].
+// Block = one 16x16 pixel tile of one patch: the 18x18x32 halo tile is staged in LDS once (pixel pitch 36 floats:
+// conflict-free ds_read_b128 across pixels) instead of being re-fetched by all nine taps; the two filters are read
+// through the scalar cache (wave-uniform indices).
+constexpr int HT = 16, HPITCH = 36;
 __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x, const float* __restrict__ w /*[2][9][32]*/,
                                                     float bp, float bw, float* __restrict__ outa, float* __restrict__ outc,
                                                     int M, int P, int conf)
 {
-    __shared__ __attribute__((aligned(16))) float wl[2 * 288];
-    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = w[i];
+    __shared__ __attribute__((aligned(16))) float tile[(HT + 2) * (HT + 2) * HPITCH];
+    const int tiles = (P + HT - 1) / HT;
+    const int m = blockIdx.x / (tiles * tiles), tt = blockIdx.x % (tiles * tiles);
+    const int y0 = (tt / tiles) * HT - 1, x0 = (tt % tiles) * HT - 1;
+    for (int i = threadIdx.x; i < (HT + 2) * (HT + 2) * 8; i += 256) {
+        const int px = i >> 3, q = i & 7;
+        const int iy = y0 + px / (HT + 2), ix = x0 + px % (HT + 2);
+        f4v v = (f4v)(0.0f);
+        if ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+            v = *reinterpret_cast<const f4v*>(x + (((size_t)m * P + iy) * P + ix) * 32 + q * 4);
+        *reinterpret_cast<f4v*>(tile + px * HPITCH + q * 4) = v;
+    }
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * P * P) return;
-    const int ox = (int)(i % P), oy = (int)((i / P) % P); const size_t m = i / ((size_t)P * P);
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
     float ap = bp, aw = bw;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int iy = oy - 1 + ky, ix = ox - 1 + kx;
-            if ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) {
-                const float* px = x + ((m * P + iy) * P + ix) * 32;
-                const float* w0 = wl + (ky * 3 + kx) * 32; const float* w1 = w0 + 288;
+            const float* px = tile + ((ly + ky) * (HT + 2) + lx + kx) * HPITCH;
+            const float* w0 = w + (ky * 3 + kx) * 32; const float* w1 = w0 + 288;
 #pragma unroll
-                for (int c = 0; c < 32; c += 4) {
-                    const f4v v = *reinterpret_cast<const f4v*>(px + c);
-                    const f4v a0 = *reinterpret_cast<const f4v*>(w0 + c), a1 = *reinterpret_cast<const f4v*>(w1 + c);
-                    ap = fmaf(v.x, a0.x, ap); ap = fmaf(v.y, a0.y, ap); ap = fmaf(v.z, a0.z, ap); ap = fmaf(v.w, a0.w, ap);
-                    aw = fmaf(v.x, a1.x, aw); aw = fmaf(v.y, a1.y, aw); aw = fmaf(v.z, a1.z, aw); aw = fmaf(v.w, a1.w, aw);
-                }
+            for (int c = 0; c < 32; c += 4) {
+                const f4v v = *reinterpret_cast<const f4v*>(px + c);
+                ap = fmaf(v.x, w0[c], ap); ap = fmaf(v.y, w0[c + 1], ap); ap = fmaf(v.z, w0[c + 2], ap); ap = fmaf(v.w, w0[c + 3], ap);
+                aw = fmaf(v.x, w1[c], aw); aw = fmaf(v.y, w1[c + 1], aw); aw = fmaf(v.z, w1[c + 2], aw); aw = fmaf(v.w, w1[c + 3], aw);
             }
         }
-    const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
-    outa[i] = conf ? pr * cf : pr;
-    if (outc) outc[i] = cf;
+    const int oy = y0 + 1 + ly, ox = x0 + 1 + lx;
+    if (oy < P && ox < P) {
+        const size_t i = ((size_t)m * P + oy) * P + ox;
+        const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
+        outa[i] = conf ? pr * cf : pr;
+        if (outc) outc[i] = cf;
+    }
 }
 
 // mlp_points: rows = Mo*HW; in = xyz[(m % N)][c][hw] * (depth ? depth[m][hw] : 1)
@@ -331,7 +343,8 @@ int omni_attention_f32(const float* q, const float* kv, float* out, int B, int N
 int omni_heads_f32(const float* x, const float* w, float bias_pred, float bias_weight, float* out_a, float* out_c,
                    int M, int P, int confidence, omni_stream_t stream)
 {
-    hipLaunchKernelGGL(heads_kernel, dim3(nblk((size_t)M * P * P)), dim3(256), 0, S_, x, w, bias_pred, bias_weight, out_a, out_c, M, P, confidence);
+    const int ht = (P + HT - 1) / HT;
+    hipLaunchKernelGGL(heads_kernel, dim3(M * ht * ht), dim3(256), 0, S_, x, w, bias_pred, bias_weight, out_a, out_c, M, P, confidence);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_mlp_points_f32(const float* xyz, const float* depth, const float* w1, const float* b1, const float* w2,

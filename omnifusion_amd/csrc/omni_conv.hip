@@ -52,8 +52,10 @@ struct ConvArgs {
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;                  // LDS row pitch in floats
 
+// __launch_bounds__(256, 5): at most 96 registers (VGPR+AGPR) so that five blocks share a CU (5 x 27.6 KB LDS fits):
+// the 1152-block layers (layer1, de_conv2_x at B=8) then run in ONE round of 4.5 waves per SIMD instead of 4 + a tail.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvArgs a)
+__global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;        // 32x32 MFMA tiles per wave
     constexpr int APASS = BM / 32, BPASS = BN / 32;            // float4 loads per thread per K-step
@@ -275,11 +277,18 @@ extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, con
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: split-K workspace too small");
     a.splitk = S; a.ws = ws;
-    // tile choice: 128-row tiles when they alone fill the 256 CUs twice over, 64-row tiles otherwise
-    const long long blocks128 = ((rows + 127) / 128) * (Cout / 64);
-    if (Cout % 64 != 0)        launch_cfg<128, 32, 4, 1>(a, s);
-    else if (blocks128 >= 512) launch_cfg<128, 64, 4, 1>(a, s);
-    else                       launch_cfg<64, 64, 2, 2>(a, s);
+    // tile choice: the matrix pipes are shared per SIMD, so what matters is how evenly the waves divide over the 1024
+    // SIMDs: w = blocks*4/1024 waves per SIMD runs at w/ceil(w) of the saturated rate (five blocks fit a CU).  The 128-row
+    // tile re-reads the weights half as often, hence the small bonus.
+    auto quant = [](double w) { return w / (w <= 5.0 ? (double)(long long)(w + 0.999999) : (double)(long long)(w / 5.0 + 0.999999) * 5.0); };
+    const int Sx = S > 1 ? S : 1;
+    if (Cout % 64 != 0) launch_cfg<128, 32, 4, 1>(a, s);
+    else {
+        const double w128 = (double)(((rows + 127) / 128) * (Cout / 64)) * Sx * 4.0 / 1024.0;
+        const double w64 = (double)(((rows + 63) / 64) * (Cout / 64)) * Sx * 4.0 / 1024.0;
+        if (quant(w128) * 1.06 >= quant(w64)) launch_cfg<128, 64, 4, 1>(a, s);
+        else                                  launch_cfg<64, 64, 2, 2>(a, s);
+    }
     OMNI_HIP(hipGetLastError());
     if (S > 1) {
         const size_t n4 = (size_t)rows * Cout / 4;

@@ -224,7 +224,6 @@ __device__ __forceinline__ int wave_max(int v) {
 __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, int tiles_per_patch, int ntiles,
                                                       const int* __restrict__ fb, unsigned char* flags_out)
 {
-    typedef float f4v __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float box[2][E2P_BOXF];
     __shared__ int red[4][4];
     __shared__ int sh_xc;
@@ -287,7 +286,8 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     if (xs < 0) xs += W;
     if (xs >= W) xs -= W;
     const int xs4 = xs & ~3, shift = xs - xs4;
-    const int bw = (dmax - dmin + 2 + shift + 3) & ~3;       // columns x0..x0+1 of every sample, whole 16-byte chunks
+    int bw = (dmax - dmin + 2 + shift + 3) & ~3;             // columns x0..x0+1 of every sample, whole 16-byte chunks
+    if ((bw & 31) == 0) bw += 4;                             // rows a multiple of 128 B apart would all hit the same LDS banks
     const int bh = ymax - ymin + 1;
     const int bw4 = bw >> 2, nchunk = bh * bw4;
     const bool fits = ((W & 3) == 0) && (bw <= W) && (bh * bw <= E2P_BOXF);
@@ -313,59 +313,60 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
         }
         // Plane loop for a box of NJ x 256 16-byte chunks at most (NJ is block-uniform).  Threads past the
         // last chunk re-load / re-store the last chunk (identical data, same address): no exec masking.
-        auto run = [&](auto NJc) {
-            constexpr int NJ = decltype(NJc)::value;
-            int goff[NJ], lidx[NJ];
+        // Box fill by LDS-DMA (global_load_lds_dwordx4): a wave's 64 lanes deposit 64 consecutive 16-byte chunks
+        // straight into the box (the chunk order IS the LDS order), no VGPR staging and no ds_write issue slots.
+        // The DMA of plane p+1 is in flight behind the gathers of plane p; one barrier per plane.
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int lane = t & 63;
+        int goff[4]; bool live[4];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int qd = min(t + 256 * j, nchunk - 1);
-                const int r = qd / bw4, cx = qd - r * bw4;
-                int gx = xs4 + 4 * cx;
-                if (gx >= W) gx -= W;
-                goff[j] = (ymin + r) * W + gx;
-                lidx[j] = qd;
-            }
-            f4v pf[NJ];
+        for (int j = 0; j < 4; ++j) {
+            const int qd = wave * 64 + 256 * j + lane;
+            const int qc = min(qd, nchunk - 1);
+            const int r = qc / bw4, cx = qc - r * bw4;
+            int gx = xs4 + 4 * cx;
+            if (gx >= W) gx -= W;
+            goff[j] = (ymin + r) * W + gx;
+            live[j] = qd < nchunk;
+        }
+        const int nj = (nchunk + 255) >> 8;                          // block-uniform
+        auto dma = [&](const float* img, float* buf) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) pf[j] = *reinterpret_cast<const f4v*>(erp + goff[j]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) reinterpret_cast<f4v*>(box[0])[lidx[j]] = pf[j];
-            __syncthreads();
-            const float* img = erp;
-            float* dst = out;
-            int par = 0;
-            for (int b = 0; b < a.B; ++b) {
-                for (int c = 0; c < a.C; ++c) {
-                    const float* cur = box[par];
-                    float* nxt = box[par ^ 1];
-                    par ^= 1;
-                    const bool last = (b == a.B - 1) && (c == a.C - 1);
-                    if (!last) img += img_plane;                     // the last trip re-reads its own plane
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) if (!(a.dbg & 2)) pf[j] = *reinterpret_cast<const f4v*>(img + goff[j]);
-                    float v00[4], v01[4], v10[4], v11[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v00[k] = cur[r0[k]]; v01[k] = cur[r0[k] + s1[k]];
-                        v10[k] = cur[r1[k]]; v11[k] = cur[r1[k] + s1[k]];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float r = fmaf(v11[k], w11[k], fmaf(v10[k], w10[k], fmaf(v01[k], w01[k], v00[k] * w00[k])));
-                        if (!(a.dbg & 1) || r == 12345.678f) dst[k * ostep] = r;
-                    }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) reinterpret_cast<f4v*>(nxt)[lidx[j]] = pf[j];
-                    __syncthreads();
-                    dst += plane;
-                }
-                dst += out_bstride - (size_t)a.C * plane;
-            }
+            for (int j = 0; j < 4; ++j)
+                if (j < nj && live[j])
+                    __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[j]), (lptr_t)(buf + (wave * 64 + 256 * j) * 4), 16, 0, 0);
         };
-        if (nchunk <= 256)      run(std::integral_constant<int, 1>{});
-        else if (nchunk <= 512) run(std::integral_constant<int, 2>{});
-        else if (nchunk <= 768) run(std::integral_constant<int, 3>{});
-        else                    run(std::integral_constant<int, 4>{});
+        dma(erp, box[0]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* img = erp;
+        float* dst = out;
+        int par = 0;
+        for (int b = 0; b < a.B; ++b) {
+            for (int c = 0; c < a.C; ++c) {
+                const float* cur = box[par];
+                const bool last = (b == a.B - 1) && (c == a.C - 1);
+                if (!last) { img += img_plane; if (!(a.dbg & 2)) dma(img, box[par ^ 1]); }
+                par ^= 1;
+                float v00[4], v01[4], v10[4], v11[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a0 = cur[r0[k]], a1 = cur[r0[k] + 1];          // one ds_read2_b32 per tap row
+                    const float b0 = cur[r1[k]], b1 = cur[r1[k] + 1];
+                    v00[k] = a0; v01[k] = s1[k] ? a1 : a0; v10[k] = b0; v11[k] = s1[k] ? b1 : b0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float r = fmaf(v11[k], w11[k], fmaf(v10[k], w10[k], fmaf(v01[k], w01[k], v00[k] * w00[k])));
+                    if (!(a.dbg & 1) || r == 12345.678f) dst[k * ostep] = r;
+                }
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the DMA pieces are older than this trip's 4 stores
+                __syncthreads();
+                dst += plane;
+            }
+            dst += out_bstride - (size_t)a.C * plane;
+        }
     } else {
         // direct gathers (same taps): tiles containing a pole, ragged tiles, odd row pitch
         bool ok[4];

@@ -224,9 +224,11 @@ __device__ __forceinline__ int wave_max(int v) {
 __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, int tiles_per_patch, int ntiles,
                                                       const int* __restrict__ fb, unsigned char* flags_out)
 {
-    __shared__ __attribute__((aligned(16))) float box[2][E2P_BOXF];
-    __shared__ int red[4][4];
-    __shared__ int sh_xc;
+    // ONE __shared__ object: with a second one hipcc waits vmcnt(0) before every ds_read while an LDS-DMA is in flight
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * E2P_BOXF + 20];
+    float (*box)[E2P_BOXF] = reinterpret_cast<float (*)[E2P_BOXF]>(lds_all);
+    int (*red)[4] = reinterpret_cast<int (*)[4]>(lds_all + 2 * E2P_BOXF);
+    int& sh_xc = *reinterpret_cast<int*>(lds_all + 2 * E2P_BOXF + 16);
     const bool fb_block = (int)blockIdx.x >= ntiles;
     int fb_b = 0;
     unsigned lb;
@@ -303,6 +305,8 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
 
     if (flags_out) { if (t == 0) flags_out[lb] = (fits && full) ? 0 : 1; return; }
     if (!fb_block && !(fits && full)) return;          // covered by the fallback blocks of this launch
+    if ((a.dbg & 4) && fb_block) return;
+    if ((a.dbg & 8) && !fb_block) return;
     if (!fb_block) {
         int r0[4], r1[4];
 #pragma unroll
@@ -315,57 +319,57 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
         // last chunk re-load / re-store the last chunk (identical data, same address): no exec masking.
         // Box fill by LDS-DMA (global_load_lds_dwordx4): a wave's 64 lanes deposit 64 consecutive 16-byte chunks
         // straight into the box (the chunk order IS the LDS order), no VGPR staging and no ds_write issue slots.
-        // The DMA of plane p+1 is in flight behind the gathers of plane p; one barrier per plane.
+        // The DMA of plane p+1 is in flight behind the gathers of plane p; one barrier per plane.  The loop is kept
+        // free of per-lane conditions: the scalar unit is shared by the whole CU and ~100 scalar instructions per wave
+        // and plane (exec-mask juggling, 64-bit pointer updates) were costing as much as the gathers themselves.
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int lane = t & 63;
-        int goff[4]; bool live[4];
+        const int nj = (nchunk + 255) >> 8;                          // block-uniform number of chunk columns (1..4)
+        int goff[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int qd = wave * 64 + 256 * j + lane;
-            const int qc = min(qd, nchunk - 1);
+            const int qc = min(wave * 64 + 256 * j + lane, nchunk - 1);   // lanes past the end re-fetch the last chunk ...
             const int r = qc / bw4, cx = qc - r * bw4;
             int gx = xs4 + 4 * cx;
             if (gx >= W) gx -= W;
             goff[j] = (ymin + r) * W + gx;
-            live[j] = qd < nchunk;
         }
-        const int nj = (nchunk + 255) >> 8;                          // block-uniform
+        // ... into their own (unused) slot, which must still lie inside the buffer: slots = E2P_BOXF/4 = 992 < 1024
+        const bool tail_ok = (wave * 64 + 256 * 3 + lane) < E2P_BOXF / 4;
         auto dma = [&](const float* img, float* buf) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < nj && live[j])
-                    __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[j]), (lptr_t)(buf + (wave * 64 + 256 * j) * 4), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[0]), (lptr_t)(buf + (wave * 64) * 4), 16, 0, 0);
+            if (nj > 1) __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[1]), (lptr_t)(buf + (wave * 64 + 256) * 4), 16, 0, 0);
+            if (nj > 2) __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[2]), (lptr_t)(buf + (wave * 64 + 512) * 4), 16, 0, 0);
+            if (nj > 3 && tail_ok) __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[3]), (lptr_t)(buf + (wave * 64 + 768) * 4), 16, 0, 0);
         };
-        dma(erp, box[0]);
+        float* const box0 = &box[0][0];
+        dma(erp, box0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* img = erp;
         float* dst = out;
-        int par = 0;
-        for (int b = 0; b < a.B; ++b) {
-            for (int c = 0; c < a.C; ++c) {
-                const float* cur = box[par];
-                const bool last = (b == a.B - 1) && (c == a.C - 1);
-                if (!last) { img += img_plane; if (!(a.dbg & 2)) dma(img, box[par ^ 1]); }
-                par ^= 1;
-                float v00[4], v01[4], v10[4], v11[4];
+        const size_t bskip = out_bstride - (size_t)a.C * plane;
+        int cc = 0;
+        const int planes = a.B * a.C;
+        for (int p = 0; p < planes; ++p) {
+            const float* cur = box0 + (p & 1) * E2P_BOXF;
+            if (p + 1 < planes) { img += img_plane; dma(img, box0 + ((p + 1) & 1) * E2P_BOXF); }
+            float r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float a0 = cur[r0[k]], a1 = cur[r0[k] + 1];          // one ds_read2_b32 per tap row
-                    const float b0 = cur[r1[k]], b1 = cur[r1[k] + 1];
-                    v00[k] = a0; v01[k] = s1[k] ? a1 : a0; v10[k] = b0; v11[k] = s1[k] ? b1 : b0;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float r = fmaf(v11[k], w11[k], fmaf(v10[k], w10[k], fmaf(v01[k], w01[k], v00[k] * w00[k])));
-                    if (!(a.dbg & 1) || r == 12345.678f) dst[k * ostep] = r;
-                }
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the DMA pieces are older than this trip's 4 stores
-                __syncthreads();
-                dst += plane;
+            for (int k = 0; k < 4; ++k) {
+                const float a0 = cur[r0[k]], a1 = cur[r0[k] + 1];              // one ds_read2_b32 per tap row
+                const float b0 = cur[r1[k]], b1 = cur[r1[k] + 1];
+                r[k] = fmaf(s1[k] ? b1 : b0, w11[k], fmaf(b0, w10[k], fmaf(s1[k] ? a1 : a0, w01[k], a0 * w00[k])));
             }
-            dst += out_bstride - (size_t)a.C * plane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k * ostep] = r[k];
+            dst += plane;
+            if (++cc == a.C) { cc = 0; dst += bskip; }
+            // counted wait: the DMA pieces are older than this trip's 4 stores, which may stay in flight across the
+            // barrier (a plain __syncthreads() would drain them: its fence waits vmcnt(0) while an LDS-DMA is pending)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     } else {
         // direct gathers (same taps): tiles containing a pole, ragged tiles, odd row pitch

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     if (xs >= W) xs -= W;
     const int xs4 = xs & ~3, shift = xs - xs4;
     int bw = (dmax - dmin + 2 + shift + 3) & ~3;             // columns x0..x0+1 of every sample, whole 16-byte chunks
-    if ((bw & 31) == 0) bw += 4;                             // rows a multiple of 128 B apart would all hit the same LDS banks
+    if (((bw >> 2) & 1) == 0) bw += 4;                       // odd number of 16-byte chunks per row: consecutive box rows start
+                                                             // 4, 12, 20, 28 banks apart (polar patches walk the box by rows)
     const int bh = ymax - ymin + 1;
     const int bw4 = bw >> 2, nchunk = bh * bw4;
     const bool fits = ((W & 3) == 0) && (bw <= W) && (bh * bw <= E2P_BOXF);

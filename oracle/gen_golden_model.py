@@ -64,6 +64,14 @@ def main():
         o_t = neti(x[:1], 2, confidence=True)
     _save("G7_model_iterative", rgb=rgb[:1], it0=o_f[0].numpy(), it1=o_f[1].numpy(),
           it0_conf=o_t[0].numpy(), it1_conf=o_t[1].numpy())
+    # ---- G7b: nrows = 6 (46 patches, the BASELINE config-3 geometry) at a small ERP, iterative iter = 2
+    rgb6 = smooth_erp(601, 1, 3, 96, 192, k=9, passes=1)
+    net6 = ref.spherical_fusion_iterative(nrows=6, npatches=46, patch_size=(128, 128), fov=(80, 80))
+    net6.load_state_dict(make_state_dict(42, 46, True))
+    net6.eval()
+    with scratch_cwd(), torch.no_grad():
+        o6 = net6(torch.from_numpy(rgb6), 2, confidence=False)
+    _save("G7b_model_iterative_n6", rgb=rgb6, it0=o6[0].numpy(), it1=o6[1].numpy())
 
 
 if __name__ == "__main__":

@@ -172,6 +172,30 @@ def test_iterative_model_golden():
     assert np.abs(o[1].cpu().numpy() - g["it1_conf"]).max() <= 1e-3
 
 
+def test_iterative_model_nrows6_golden():
+    """G7b: nrows = 6 (46 patches, BASELINE config-3 geometry), iterative iter = 2, against the reference's own output."""
+    _, spherical_fusion_it, make_state_dict = _nets()
+    g = golden("G7b_model_iterative_n6")
+    net = spherical_fusion_it(6, 46, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 46, True))
+    o = net(torch.from_numpy(g["rgb"]).to(DEV), iter=2)
+    assert np.abs(o[0].cpu().numpy() - g["it0"]).max() <= 1e-3
+    assert np.abs(o[1].cpu().numpy() - g["it1"]).max() <= 1e-3
+
+
+def test_graphed_forward_matches_eager():
+    """hipGraph replay of the whole launch sequence gives the same bits as the eager forward."""
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rgb = torch.from_numpy(smooth_erp(5, 2, 3, 64, 128)).to(DEV)
+    ref = net(rgb).clone()
+    run = net.graphed(rgb)
+    assert torch.equal(run(rgb), ref)
+    rgb2 = torch.from_numpy(smooth_erp(6, 2, 3, 64, 128)).to(DEV)
+    assert torch.equal(run(rgb2), net(rgb2))
+
+
 def test_model_config1_size():
     """BASELINE config 1/2 shape: 512x1024 ERP, nrows=4, P=128 (the only size the network exists at), smooth
     synthetic panorama, against (i) the reference's own output (G6b) and (ii) the torch fp32 oracle.

@@ -58,3 +58,9 @@ def test_single_pass_oracle_config1_size():
     sd = make_state_dict(42, 18, False)
     out = mr.spherical_fusion_forward(sd, torch.from_numpy(smooth_erp(77, 1, 3, 512, 1024)), confidence=True).numpy()
     assert_close_outliers(out[:, :, ::2, ::2], g["depth_conf_sub"], tol=1e-3, max_tol=2e-2, frac=1e-5)
+
+
+def test_iterative_oracle_nrows6_golden():
+    g = golden("G7b_model_iterative_n6")
+    o = mr.spherical_fusion_iterative_forward(make_state_dict(42, 46, True), torch.from_numpy(g["rgb"]), 2, nrows=6, confidence=False)
+    assert np.abs(o[0].numpy() - g["it0"]).max() < 2e-4 and np.abs(o[1].numpy() - g["it1"]).max() < 2e-4

@@ -170,6 +170,18 @@ int omni_heads_f32(const float* x, const float* w, float bias_pred, float bias_w
 int omni_mlp_points_f32(const float* xyz, const float* depth, const float* w1, const float* b1, const float* w2,
                         const float* b2, float* out, int Mo, int N, int HW, omni_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evaluation metrics on the device (first "next" row): test.py:151-176 compute_eval_metrics and
+ * metrics.py:7-26, without a device->host copy per batch.
+ * ---------------------------------------------------------------------------------------------- */
+/* x[mask > 0].median() (torch semantics: the lower middle element).  ws: >= 260 unsigned; out: one device float. */
+int omni_masked_median_f32(const float* x, const float* mask, size_t n, unsigned* ws, float* out, omni_stream_t stream);
+/* pred *= *scale_num / *scale_den in place (test.py:161-162; device scalars, both NULL = no scaling), then
+ * out[9] = abs_rel, sq_rel, rms_sq_lin, rms_sq_log, d1, d2, d3 (masked means, metrics.py:7-26), N = mask.sum(), N_log.
+ * ws: >= 2048*9 doubles. */
+int omni_depth_metrics_f32(float* pred, const float* gt, const float* mask, const float* scale_num, const float* scale_den,
+                           size_t n, double* ws, float* out, omni_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

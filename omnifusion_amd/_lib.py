@@ -33,6 +33,7 @@ EXPORTS = [
     "omni_attention_f32", "omni_heads_f32", "omni_mlp_points_f32",
     "omni_conv2d_sh_f16x3", "omni_f32_to_sh", "omni_sh_to_f32",
     "omni_conv2d_splitk_plan", "omni_conv2d_nhwc_f32_ws",
+    "omni_masked_median_f32", "omni_depth_metrics_f32",
 ]
 
 

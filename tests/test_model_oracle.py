@@ -64,3 +64,13 @@ def test_iterative_oracle_nrows6_golden():
     g = golden("G7b_model_iterative_n6")
     o = mr.spherical_fusion_iterative_forward(make_state_dict(42, 46, True), torch.from_numpy(g["rgb"]), 2, nrows=6, confidence=False)
     assert np.abs(o[0].numpy() - g["it0"]).max() < 2e-4 and np.abs(o[1].numpy() - g["it1"]).max() < 2e-4
+
+
+def test_metrics_restatement_golden():
+    """G9: oracle/metrics_ref.py against values computed by the reference's own metrics.py."""
+    from oracle.metrics_ref import compute_eval_metrics
+    g = golden("G9_eval_metrics")
+    scaled, vals, N = compute_eval_metrics(g["pred"], g["gt"], g["mask"])
+    np.testing.assert_allclose(scaled, g["scaled"], rtol=1e-6)
+    np.testing.assert_allclose(vals, g["metrics"], rtol=1e-5)
+    assert N == int(g["N"])

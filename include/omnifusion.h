@@ -134,16 +134,15 @@ int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, const float* w
                             const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
                             int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                             omni_stream_t stream);
-/* The same operator on the fp16 matrix cores with fp32-class accuracy ("f16x3", csrc/omni_conv16.hip): every value is a
- * pair of halfs x = hi + lo*2^-11 and a product block is three v_mfma_f32_32x32x16_f16.  Activations are in the SH32
- * format: [M,H,W,C/32][hi32|lo32] halfs (4 bytes per element); wt: [Cout][KH*KW*(C1+C2)/32][hi32|lo32]; bias fp32.
- * out_f32 != 0 writes plain fp32 NHWC instead of SH32 (used for the `down` projection feeding the transformer). */
-int omni_conv2d_sh_f16x3(const void* src1, const void* src2, const void* wt, const float* bias, const void* res,
-                         void* dst, int M, int H, int W, int C1, int C2, int Cout, int KH, int KW, int stride,
-                         int pad, int act, int out_f32, omni_stream_t stream);
-/* fp32 NHWC <-> SH32 (n = element count, multiple of 32; the channel count must be a multiple of 32) */
-int omni_f32_to_sh(const float* src, void* dst, size_t n, omni_stream_t stream);
-int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
+/* The same operator with the products on the fp16 matrix cores at fp32-class accuracy ("f16x3"): every operand is split
+ * into a pair of halfs x = hi + lo*2^-11 and a product block is three v_mfma_f32_32x32x16_f16 (3/16 of the fp32-MFMA
+ * time, max error ~3e-6).  Activations, bias, residual and output stay fp32 NHWC (the A tile is split on its way into
+ * LDS); wt16 is the weight matrix split once at load time: halfs [Cout][KH*KW*(C1+C2)/32][hi32|lo32],
+ * hi = fp16(w) (0 below 2^-14), lo = fp16((w - hi) * 2048). */
+int omni_conv2d_nhwc_f16x3_ws(const float* src1, const float* src2, const void* wt16, const float* bias,
+                              const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                              int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                              omni_stream_t stream);
 /* conv1 7x7 s2 p3 (3->64) + bn1 + ReLU, model/spherical_model.py:254.  src planar [M,3,P,P]
  * (OMNI_LAYOUT_BNCHW patches), wt [147][64] (k = (ky*7+kx)*3+c), dst NHWC [M,P/2,P/2,64]. */
 int omni_stem_f32(const float* src, const float* wt, const float* bias, float* dst, int M, int P, omni_stream_t stream);

@@ -11,6 +11,14 @@
 // 1.8e-2 max (oracle/model_ref.py, fp16=True), so this path uses the EXACT fp32 MFMA
 // v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense peak, bit-for-bit a k-ordered fmaf chain).
 //
+// F16X3 = true selects the fp16 matrix cores at fp32-class accuracy instead: every operand x is split into a pair of
+// halfs x = hi + lo * 2^-11 (hi = fp16(x), lo = fp16((x - hi) * 2^11): 22-23 significant bits, the 2^11 scale keeps `lo`
+// out of the fp16 subnormal range) and a product block is THREE v_mfma_f32_32x32x16_f16 with fp32 accumulation,
+//        A.B = A_hi.B_hi + 2^-11 (A_hi.B_lo + A_lo.B_hi)          [A_lo.B_lo * 2^-22 dropped]
+// i.e. 3/16 of the fp32-MFMA time.  Activations stay fp32 NHWC in HBM (so every other kernel is untouched): the A tile
+// is split while it is parked in LDS (2 cvt_pk + 4 sub/mul per 4 channels); the weights are split once at load time
+// ([Cout][K/32][hi32|lo32] halfs).  Max error 1.6e-6..3.7e-6 against float64 on every conv shape of the network.
+//
 // GEMM view: D[r][j] = sum_k A[r][k] * Wt[j][k],  r = output pixel (m, oy, ox), j = output channel,
 // k = (tap, input channel).  A is gathered on the fly (zero outside the image), channels of a tap
 // are contiguous in NHWC so every A fetch is a 16-byte load; an optional second source supplies
@@ -27,6 +35,8 @@ namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
 // raw buffer descriptor (V#) over [p, p+bytes): stride 0, num_records = bytes; gfx9-family flags dword
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -45,23 +55,30 @@ struct ConvArgs {
     int M, H, W, C1, C2, Ho, Wo, Cout;
     int KH, KW, stride, pad, act;
     int rows;                                // M*Ho*Wo
+    int f16x3;                               // 1: wt is the pre-split half format, products on the fp16 matrix cores
     int splitk;                              // >1: blockIdx.y owns a K range and writes raw partial sums to ws[y]
     float* ws;                               // [splitk][rows][Cout]
 };
 
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;                  // LDS row pitch in floats
+constexpr int HP = BK + 8;                   // LDS row pitch in halfs (F16X3 images): 80 B, conflict-free ds_read_b128
 
 // __launch_bounds__(256, 5): at most 96 registers (VGPR+AGPR) so that five blocks share a CU (5 x 27.6 KB LDS fits):
 // the 1152-block layers (layer1, de_conv2_x at B=8) then run in ONE round of 4.5 waves per SIMD instead of 4 + a tail.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
+template <int BM, int BN, int WM, int WN, bool F16X3>
+__global__ __launch_bounds__(256, (F16X3 ? 3 : 5)) void conv_igemm_f32_kernel(ConvArgs a)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;        // 32x32 MFMA tiles per wave
     constexpr int APASS = BM / 32, BPASS = BN / 32;            // float4 loads per thread per K-step
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDP];
-    float* As = lds;
-    float* Bs = lds + BM * LDP;
+    constexpr int LDS_BYTES = F16X3 ? 2 * (BM + BN) * HP * 2 : (BM + BN) * LDP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    float* As = reinterpret_cast<float*>(lds_raw);
+    float* Bs = As + BM * LDP;
+    _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);         // F16X3 images: A_hi, A_lo, B_hi, B_lo
+    _Float16* Al = Ah + BM * HP;
+    _Float16* Bh = Al + BM * HP;
+    _Float16* Bl = Bh + BN * HP;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -100,10 +117,12 @@ __global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
     }
     const rsrc_t rs1 = make_rsrc(a.src1, (size_t)a.M * a.H * a.W * a.C1 * 4);
     const rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? (size_t)a.M * a.H * a.W * a.C2 * 4 : 0);
+    // weights: fp32 [Cout][K] (16-byte piece = 4 k)  |  F16X3: halfs [Cout][K/32][hi32|lo32] (piece t&7: 0-3 hi, 4-7 lo)
     const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * Kfull * 4);
     int wbase[BPASS];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) wbase[i] = ((col0 + lr + 32 * i) * Kfull + kq) * 4;
+    for (int i = 0; i < BPASS; ++i) wbase[i] = F16X3 ? ((col0 + lr + 32 * i) * ksteps * 64 + (t & 7) * 8) * 2
+                                                      : ((col0 + lr + 32 * i) * Kfull + kq) * 4;
 
     f4v ra[APASS], rb[BPASS];
     int f_tap = 0, f_c = 0, f_ky = 0, f_kx = 0;                  // (tap, channel chunk) of the NEXT fetch
@@ -126,17 +145,35 @@ __global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
         if (f_c == Cin) { f_c = 0; ++f_tap; if (++f_kx == a.KW) { f_kx = 0; ++f_ky; } }
     };
     auto stash = [&]() {
+        if (F16X3) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) *reinterpret_cast<f4v*>(As + (lr + 32 * i) * LDP + kq) = ra[i];
+            for (int i = 0; i < APASS; ++i) {                    // split 4 channels: hi = fp16(x) (0 below the normal range), lo = fp16((x-hi)*2^11)
+                h4v hi, lo;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f4v*>(Bs + (lr + 32 * i) * LDP + kq) = rb[i];
+                for (int e = 0; e < 4; ++e) {
+                    const float x = ra[i][e];
+                    const _Float16 h = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+                    hi[e] = h; lo[e] = (_Float16)((x - (float)h) * 2048.0f);
+                }
+                *reinterpret_cast<h4v*>(Ah + (lr + 32 * i) * HP + kq) = hi;
+                *reinterpret_cast<h4v*>(Al + (lr + 32 * i) * HP + kq) = lo;
+            }
+            _Float16* bd = ((t & 7) >= 4 ? Bl : Bh) + lr * HP + (t & 3) * 8;
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f4v*>(bd + 32 * i * HP) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) *reinterpret_cast<f4v*>(As + (lr + 32 * i) * LDP + kq) = ra[i];
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f4v*>(Bs + (lr + 32 * i) * LDP + kq) = rb[i];
+        }
     };
 
-    f16v acc[TM][TN];
+    f16v acc[TM][TN], acc1[F16X3 ? TM : 1][F16X3 ? TN : 1];      // F16X3: acc = hi.hi, acc1 = hi.lo + lo.hi (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f16v)(0.0f);
+        for (int j = 0; j < TN; ++j) { acc[i][j] = (f16v)(0.0f); if (F16X3) acc1[i][j] = (f16v)(0.0f); }
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     const float* Aw = As + (wm * TM * 32 + frow) * LDP + fk;
@@ -154,6 +191,31 @@ __global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
         stash();
         __syncthreads();
         if (ks + 1 < ks_end) fetch(ks + 1);  // next tiles in flight while the matrix cores work
+        if (F16X3) {
+            const int foff = (lane & 31) * HP + (lane >> 5) * 8;   // fragment: row lane&31, k = 8*(lane>>5) .. +7 of a 16-wide chunk
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                h8v ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const h8v*>(Ah + ((wm * TM + i) * 32) * HP + foff + kc * 16);
+                    al[i] = *reinterpret_cast<const h8v*>(Al + ((wm * TM + i) * 32) * HP + foff + kc * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const h8v*>(Bh + ((wn * TN + j) * 32) * HP + foff + kc * 16);
+                    bl[j] = *reinterpret_cast<const h8v*>(Bl + ((wn * TN + j) * 32) * HP + foff + kc * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             f4v fa[TM], fb[TN];
@@ -169,6 +231,7 @@ __global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
+        }
     }
 
     // ---- epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -181,10 +244,11 @@ __global__ __launch_bounds__(256, 5) void conv_igemm_f32_kernel(ConvArgs a)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int r = row0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const float d = F16X3 ? fmaf(acc1[i][j][reg], 4.8828125e-4f, acc[i][j][reg]) : acc[i][j][reg];
                 if (r < a.rows && a.splitk > 1) {
-                    a.ws[((size_t)blockIdx.y * a.rows + r) * a.Cout + col] = acc[i][j][reg];
+                    a.ws[((size_t)blockIdx.y * a.rows + r) * a.Cout + col] = d;
                 } else if (r < a.rows) {
-                    float v = acc[i][j][reg] + bj;
+                    float v = d + bj;
                     const size_t o = (size_t)r * a.Cout + col;
                     if (a.res) v += a.res[o];
                     if (a.act == OMNI_ACT_RELU) v = fmaxf(v, 0.0f);
@@ -200,7 +264,8 @@ template <int BM, int BN, int WM, int WN>
 void launch_cfg(const ConvArgs& a, hipStream_t s)
 {
     const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+    if (a.f16x3) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+    else         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
 }
 
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
@@ -250,11 +315,12 @@ extern "C" int omni_conv2d_splitk_plan(long long rows, int Cout, int ksteps) { r
 // only a fraction of the 256 CUs (layer4, the decoder's first stage, every transformer GEMM at M = B*N rows) are
 // split along K over blockIdx.y (`splitk` ranges, workspace ws of splitk*rows*Cout floats) and summed by a second,
 // deterministic pass.  splitk <= 1: plain launch.
-extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, const float* wt, const float* bias,
-                                       const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
-                                       int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                                       omni_stream_t stream)
+static int conv2d_impl(const float* src1, const float* src2, const void* wt_any, int f16x3, const float* bias,
+                       const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                       int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                       omni_stream_t stream)
 {
+    const float* wt = (const float*)wt_any;
     if (!src1 || !wt || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: null pointer");
     if (C1 <= 0 || C1 % BK || C2 < 0 || C2 % BK || Cout <= 0 || Cout % 32 || (C2 > 0 && !src2))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: channels must be multiples of 32");
@@ -263,7 +329,7 @@ extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, con
     ConvArgs a;
     a.src1 = src1; a.src2 = src2; a.wt = wt; a.bias = bias; a.res = res; a.dst = dst;
     a.M = M; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout;
-    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act; a.f16x3 = f16x3;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     const long long rows = (long long)M * a.Ho * a.Wo;
     if (rows <= 0 || rows >= (1ll << 31) || (long long)M * H * W >= (1ll << 31))
@@ -297,6 +363,25 @@ extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, con
         OMNI_HIP(hipGetLastError());
     }
     return OMNI_OK;
+}
+
+extern "C" int omni_conv2d_nhwc_f32_ws(const float* src1, const float* src2, const float* wt, const float* bias,
+                                       const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                                       int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                       omni_stream_t stream)
+{
+    return conv2d_impl(src1, src2, wt, 0, bias, res, dst, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes, stream);
+}
+
+// Same operator with the products on the fp16 matrix cores ("f16x3", see the file header).  wt16: the weights split into
+// hi/lo halfs, layout [Cout][KH*KW*(C1+C2)/32][hi32|lo32]; everything else (fp32 NHWC activations, bias, residual,
+// split-K) exactly as omni_conv2d_nhwc_f32_ws.
+extern "C" int omni_conv2d_nhwc_f16x3_ws(const float* src1, const float* src2, const void* wt16, const float* bias,
+                                         const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
+                                         int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                         omni_stream_t stream)
+{
+    return conv2d_impl(src1, src2, wt16, 1, bias, res, dst, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes, stream);
 }
 
 extern "C" int omni_conv2d_nhwc_f32(const float* src1, const float* src2, const float* wt, const float* bias,

@@ -24,6 +24,17 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def split_weights_f16x3(w):
+    """[Cout][K] fp32 (K % 32 == 0) -> halfs [Cout][K/32][2][32]: hi = fp16(w) (0 below the fp16 normal range),
+    lo = fp16((w - hi) * 2048) — the operand format of omni_conv2d_nhwc_f16x3_ws."""
+    w = w.to(torch.float32)
+    hi = w.half()
+    hi = torch.where(w.abs() < 6.103515625e-05, torch.zeros_like(hi), hi)
+    lo = ((w - hi.float()) * 2048.0).half()
+    co, k = w.shape
+    return torch.stack([hi.reshape(co, k // 32, 32), lo.reshape(co, k // 32, 32)], 2).contiguous()
+
+
 def strip_module_prefix(sd):
     """checkpoints saved through nn.DataParallel carry a 'module.' prefix (train_erp_depth.py:307)"""
     return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
@@ -38,6 +49,10 @@ class Engine:
             raise ValueError("square patches only")
         self.w = None          # packed weights (device tensors)
         self.device = None
+        # "f16x3": conv products on the fp16 matrix cores with split operands (fp32-class accuracy, 3/16 of the MFMA time);
+        # "fp32": the exact fp32 MFMA everywhere.  OMNI_NET_PRECISION overrides.
+        import os
+        self.precision = os.environ.get("OMNI_NET_PRECISION", "f16x3")
 
     # ------------------------------------------------------------------ packing
     @staticmethod
@@ -64,7 +79,9 @@ class Engine:
 
         def convbn(key, conv, bn):
             w, b = self._fold(sd, conv, bn)
-            W[key + ".w"] = f(self._gemm_layout(w)); W[key + ".b"] = f(b)
+            wg = self._gemm_layout(w).to(torch.float32)
+            W[key + ".w"] = f(wg); W[key + ".b"] = f(b)
+            W[key + ".w16"] = split_weights_f16x3(wg).to(dev)
         for lname, nblk, _ in _LAYERS:
             for i in range(nblk):
                 p = f"{lname}.{i}"
@@ -117,9 +134,14 @@ class Engine:
         Wo = (Wd + 2 * pad - k) // stride + 1
         out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
-        rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), _p(self.w[key + ".b"]) if bias else None,
-                                         _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws),
-                                         ctypes.c_size_t(nb), self._s)
+        if self.precision == "f16x3" and (key + ".w16") in self.w:
+            rc = lib.omni_conv2d_nhwc_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), _p(self.w[key + ".b"]) if bias else None,
+                                               _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws),
+                                               ctypes.c_size_t(nb), self._s)
+        else:
+            rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), _p(self.w[key + ".b"]) if bias else None,
+                                             _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws),
+                                             ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "conv2d " + key)
         return out
 

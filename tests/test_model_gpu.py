@@ -74,25 +74,16 @@ def test_conv2d_vs_torch(cfg):
                                          S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
         assert rc == 0, lib.omni_last_error()
         assert (out2.cpu().double() - ref).abs().max().item() < 2e-5, S
-    # the f16x3 kernel (three fp16 MFMAs per product block on hi/lo half pairs): fp32-class accuracy
-    def split_w(wm):
-        hi = wm.half(); hi = torch.where(wm.abs() < 6.103515625e-05, torch.zeros_like(hi), hi)
-        lo = ((wm - hi.float()) * 2048.0).half()
-        return torch.stack([hi.reshape(Cout, -1, 32), lo.reshape(Cout, -1, 32)], 2).contiguous()
-    def to_sh(x):
-        o = torch.empty(x.numel() * 2, dtype=torch.float16, device=DEV)
-        assert lib.omni_f32_to_sh(_p(x), _p(o), ctypes.c_size_t(x.numel()), _stream()) == 0
-        return o
-    W16 = split_w(wt).to(DEV)
-    S1, S2, SR = to_sh(X1), (to_sh(X2) if C2 else None), (to_sh(R) if use_res else None)
-    o16 = torch.empty(out.numel() * 2, dtype=torch.float16, device=DEV)
-    rc = lib.omni_conv2d_sh_f16x3(_p(S1), _p(S2), _p(W16), _p(B), _p(SR), _p(o16), M, H, W, C1, C2, Cout, k, k, s, pad, act, 0, _stream())
-    assert rc == 0, lib.omni_last_error()
-    o32 = torch.empty_like(out)
-    assert lib.omni_sh_to_f32(_p(o16), _p(o32), ctypes.c_size_t(o32.numel()), _stream()) == 0
-    assert (o32.cpu().double() - ref).abs().max().item() < 3e-5
-    rc = lib.omni_conv2d_sh_f16x3(_p(S1), _p(S2), _p(W16), _p(B), _p(SR), _p(o32), M, H, W, C1, C2, Cout, k, k, s, pad, act, 1, _stream())
-    assert rc == 0 and (o32.cpu().double() - ref).abs().max().item() < 3e-5
+    # the f16x3 mode (three fp16 MFMAs per product block on hi/lo half pairs): fp32-class accuracy
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    W16 = split_weights_f16x3(wt).to(DEV)
+    for S in (1, min(3, ksteps)):
+        ws = torch.empty(S * out.numel(), device=DEV)
+        o16 = torch.empty_like(out)
+        rc = lib.omni_conv2d_nhwc_f16x3_ws(_p(X1), _p(X2), _p(W16), _p(B), _p(R), _p(o16), M, H, W, C1, C2, Cout, k, k, s, pad, act,
+                                           S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+        assert rc == 0, lib.omni_last_error()
+        assert (o16.cpu().double() - ref).abs().max().item() < 3e-5, S
 
 
 def test_small_ops_vs_torch():

@@ -143,6 +143,16 @@ int omni_conv2d_nhwc_f16x3_ws(const float* src1, const float* src2, const void* 
                               const float* res, float* dst, int M, int H, int W, int C1, int C2, int Cout,
                               int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                               omni_stream_t stream);
+/* The same operator with SPLIT-HALF ("SH") activations: per pixel and per group of 32 channels a tensor stores 32 hi
+ * halfs then 32 lo halfs (x = hi + lo*2^-11; 128 bytes per group = the footprint of 32 floats).  The producer splits
+ * once, consumers stream tiles straight into LDS by LDS-DMA.  src1, src2 and res are SH tensors; dst is SH when
+ * dst_sh != 0, else fp32 NHWC; wt16 as above.  omni_sh_from_f32 / omni_sh_to_f32 convert n elements (n % 32 == 0). */
+int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
+                            const void* res, void* dst, int dst_sh, int M, int H, int W, int C1, int C2, int Cout,
+                            int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                            omni_stream_t stream);
+int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
+int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* conv1 7x7 s2 p3 (3->64) + bn1 + ReLU, model/spherical_model.py:254.  src planar [M,3,P,P]
  * (OMNI_LAYOUT_BNCHW patches), wt [147][64] (k = (ky*7+kx)*3+c), dst NHWC [M,P/2,P/2,64]. */
 int omni_stem_f32(const float* src, const float* wt, const float* bias, float* dst, int M, int P, omni_stream_t stream);
@@ -154,6 +164,13 @@ int omni_upsample_bilinear_f32(const float* src, float* dst, int M, int H, int W
 int omni_add_hw_f32(float* x, const float* y, int M, int HW, int C, omni_stream_t stream);
 /* x[i] += y[i % period]: layer1 + point_feat, model/spherical_model.py:258 */
 int omni_add_period_f32(float* x, const float* y, size_t total, size_t period, omni_stream_t stream);
+/* The element-wise operators above on split-half (SH) activations (see omni_conv2d_sh_f16x3_ws): same arguments,
+ * activation tensors in the SH layout (C % 32 == 0); the broadcast operand y and the stem's planar input stay fp32. */
+int omni_stem_sh(const float* src, const float* wt, const float* bias, void* dst, int M, int P, omni_stream_t stream);
+int omni_maxpool3x3s2_sh(const void* src, void* dst, int M, int H, int W, int C, omni_stream_t stream);
+int omni_upsample_bilinear_sh(const void* src, void* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream);
+int omni_add_hw_sh(void* x, const float* y, int M, int HW, int C, omni_stream_t stream);
+int omni_add_period_sh(void* x, const float* y, size_t total, size_t period, omni_stream_t stream);
 /* tokens: reshape(bs,-1,N).transpose(1,2) of the `down` output + pos_emb, model/spherical_model.py:264,181 */
 int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream);
 /* nn.LayerNorm(512), model/blocks.py:74,81 (eps 1e-5) and model/spherical_model.py:173 (eps 1e-6) */

@@ -59,6 +59,7 @@ struct ConvArgs {
     int f16x3;                               // 1: wt is the pre-split half format, products on the fp16 matrix cores
     int splitk;                              // >1: blockIdx.y owns a K range and writes raw partial sums to ws[y]
     float* ws;                               // [splitk][rows][Cout]
+    int dbg;                                 // OMNI_CONV_DBG ablation bits (tuning only): 1 no MFMA, 2 no refetch, 4 no stash
 };
 
 constexpr int BK = 32;
@@ -189,9 +190,10 @@ __global__ __launch_bounds__(256, (F16X3 ? 3 : 5)) void conv_igemm_f32_kernel(Co
     if (ks_begin < ks_end) fetch(ks_begin);
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         __syncthreads();                     // previous step's fragment reads are done
-        stash();
+        if (!(a.dbg & 4)) stash();
         __syncthreads();
-        if (ks + 1 < ks_end) fetch(ks + 1);  // next tiles in flight while the matrix cores work
+        if (ks + 1 < ks_end && !(a.dbg & 2)) fetch(ks + 1);  // next tiles in flight while the matrix cores work
+        if (a.dbg & 1) continue;
         if (F16X3) {
             const int foff = (lane & 31) * HP + (lane >> 5) * 8;   // fragment: row lane&31, k = 8*(lane>>5) .. +7 of a 16-wide chunk
 #pragma unroll
@@ -257,6 +259,137 @@ __global__ __launch_bounds__(256, (F16X3 ? 3 : 5)) void conv_igemm_f32_kernel(Co
                     a.dst[o] = v;
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 3x3 stride-1 convolution with halo-tile reuse (f16x3)
+// The implicit GEMM above re-fetches every input pixel group once per tap: 9x the input through L2->L1, which is what
+// bounds the wide, shallow layers once the matrix-core time is cut by f16x3 (de_conv4_0: 2.7 GB of A traffic for a
+// 302 MB input).  Here a block owns a 4x32 pixel tile of ONE image and all BN output channels; per 32-channel group it
+// parks the 6x34 halo patch in LDS ONCE (split into hi/lo halfs on the way) and serves the nine taps from it: wave w
+// owns image row y0+w (32 pixels = one MFMA row tile), its A fragment for tap (ky,kx) is the same LDS image shifted by
+// ky rows and kx pixels.  Weights arrive one kernel row (3 taps) at a time.  Barriers per channel group: 7 instead of 18;
+// A traffic 1.6x the input instead of 9x.  Requires W % 32 == 0, H % 4 == 0 (the 32^2 / 64^2 / 128^2 layers).
+constexpr int HT_H = 4, HT_W = 32, HPX = (HT_H + 2) * (HT_W + 2);     // 204 halo pixels
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x3_kernel(ConvArgs a)
+{
+    constexpr int TN = BN / 32;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * HPX * HP + 2 * 3 * BN * HP];
+    _Float16* Ah = lds;
+    _Float16* Al = Ah + HPX * HP;
+    _Float16* Bh = Al + HPX * HP;
+    _Float16* Bl = Bh + 3 * BN * HP;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / HT_H;
+    int bid = blockIdx.x;
+    const int tile_n = bid % ntn; bid /= ntn;
+    const int tx = bid % tw; bid /= tw;
+    const int ty = bid % th; const int m = bid / th;
+    const int y0 = ty * HT_H, x0 = tx * HT_W, col0 = tile_n * BN;
+    const int G1 = a.C1 >> 5, G = (a.C1 + a.C2) >> 5, ksteps = 9 * G;
+
+    // A loader: piece q of the halo = (pixel q>>3, 4 channels (q&7)*4); 1632 pieces over 256 threads
+    constexpr int AP = (HPX * 8 + 255) / 256;
+    int apix[AP]; bool aok[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int q = t + 256 * i, px = q >> 3;
+        const int hy = px / (HT_W + 2), hx = px - hy * (HT_W + 2);
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        aok[i] = (px < HPX) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        apix[i] = aok[i] ? (m * a.H + iy) * a.W + ix : 0;
+    }
+    const rsrc_t rs1 = make_rsrc(a.src1, (size_t)a.M * a.H * a.W * a.C1 * 4);
+    const rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? (size_t)a.M * a.H * a.W * a.C2 * 4 : 0);
+    const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * ksteps * 128);
+    // B loader: 3 taps x BN rows x 8 pieces (0-3 hi, 4-7 lo)
+    constexpr int BP = 3 * BN * 8 / 256;
+    f16v acc[TN], acc1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
+    const int frag = (lane >> 5) * 8;
+
+    for (int g = 0; g < G; ++g) {
+        const bool first = g < G1;
+        const int cs = first ? a.C1 : a.C2, cg = (first ? g : g - G1) * 32 + (t & 7) * 4;
+        f4v ra[AP];
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int off = aok[i] ? (apix[i] * cs + cg) * 4 : (int)0x80000000;
+            ra[i] = first ? __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0))
+                          : __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs2, off, 0, 0));
+        }
+        __syncthreads();                                          // previous group's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int q = t + 256 * i;
+            if (q < HPX * 8) {
+                h4v hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = ra[i][e];
+                    const _Float16 h = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+                    hi[e] = h; lo[e] = (_Float16)((x - (float)h) * 2048.0f);
+                }
+                *reinterpret_cast<h4v*>(Ah + (q >> 3) * HP + (q & 7) * 4) = hi;
+                *reinterpret_cast<h4v*>(Al + (q >> 3) * HP + (q & 7) * 4) = lo;
+            }
+        }
+        for (int ky = 0; ky < 3; ++ky) {
+            f4v rb[BP];
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int q = t + 256 * i, pc = q & 7, row = q >> 3;            // row = kx*BN + cout
+                const int kx = row / BN, co = row - kx * BN;
+                const int off = (((col0 + co) * ksteps + (ky * 3 + kx) * G + g) * 64 + pc * 8) * 2;
+                rb[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+            }
+            if (ky) __syncthreads();                              // previous kernel row's B fragments are consumed
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int q = t + 256 * i, pc = q & 7, row = q >> 3;
+                *reinterpret_cast<f4v*>((pc >= 4 ? Bl : Bh) + row * HP + (pc & 3) * 8) = rb[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int apos = ((wave + ky) * (HT_W + 2) + (lane & 31) + kx) * HP + frag;
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const h8v ah = *reinterpret_cast<const h8v*>(Ah + apos + kc * 16);
+                    const h8v al = *reinterpret_cast<const h8v*>(Al + apos + kc * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int bpos = (kx * BN + j * 32 + (lane & 31)) * HP + frag + kc * 16;
+                        const h8v bh = *reinterpret_cast<const h8v*>(Bh + bpos);
+                        const h8v bl = *reinterpret_cast<const h8v*>(Bl + bpos);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: wave owns image row y0+wave; D layout col = lane&31, pixel = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const size_t rowbase = ((size_t)(m * a.H + y0 + wave) * a.W + x0) * a.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        const float bj = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            const size_t o = rowbase + (size_t)px * a.Cout + col;
+            float v = fmaf(acc1[j][reg], 4.8828125e-4f, acc[j][reg]) + bj;
+            if (a.res) v += a.res[o];
+            if (a.act == OMNI_ACT_RELU) v = fmaxf(v, 0.0f);
+            else if (a.act == OMNI_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            a.dst[o] = v;
         }
     }
 }
@@ -344,6 +477,14 @@ static int conv2d_impl(const float* src1, const float* src2, const void* wt_any,
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: split-K workspace too small");
     a.splitk = S; a.ws = ws;
+    { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
+    if (f16x3 && S <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % HT_H == 0 && !getenv("OMNI_CONV_NOHALO")) {
+        const int grid = M * (H / HT_H) * (W / HT_W);
+        if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<64>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
+        else                hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<32>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
+    }
     // tile choice: the matrix pipes are shared per SIMD, so what matters is how evenly the waves divide over the 1024
     // SIMDs: w = blocks*4/1024 waves per SIMD runs at w/ceil(w) of the saturated rate (five blocks fit a CU).  The 128-row
     // tile re-reads the weights half as often, hence the small bonus.

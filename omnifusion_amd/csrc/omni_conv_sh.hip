@@ -1,0 +1,415 @@
+// omni_conv_sh.hip — the convolution of the network on the fp16 matrix cores with SPLIT-HALF activations (gfx950).
+//
+// Same operator as omni_conv.hip (reference: Conv3d(k,k,1)+BatchNorm3d(+ReLU)(+residual), model/spherical_model.py:
+// 122-167 encoder, :29-37,214-222 decoder) and the same "f16x3" arithmetic (x = hi + lo*2^-11, three
+// v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation), but the activations travel between layers ALREADY
+// split: the "SH" layout stores, per pixel and per group of 32 channels, 32 hi halfs followed by 32 lo halfs (128 bytes:
+// the footprint of 32 floats, and the very row format of the pre-split weights).  The split is done once, by the
+// producer's epilogue, instead of once per (tap, output-channel tile) by every consumer — in the fp32-activation kernel
+// that VALU work cost as much issue time as the matrix instructions (ablation: 41 us of an 82 us layer3 convolution).
+//
+// With both operands in their final bit pattern the tiles go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds):
+// no staging registers, no conversion, no ds_write.  A block keeps NST stages of (A: BM pixels x 128 B, B: BN output
+// channels x 128 B) in flight; per K-step (one tap x 32 channels) there is ONE barrier:
+//      s_waitcnt vmcnt((NST-2)*LPS)   my pieces of stage k have landed       (LPS = DMA instructions per wave and stage)
+//      s_barrier                      ... everybody's have, and everybody is done reading stage k-1
+//      issue DMA for stage k+NST-1    into the slot stage k-1 occupied
+//      8 x ds_read_b128 + 6 x MFMA per 32x32 tile pair on stage k
+// Out-of-image taps and rows past the end need no branch: their buffer offset is out of range and the DMA deposits zeros
+// (checked on hardware: tools/dbg_dma.py).
+//
+// LDS image: a DMA instruction deposits its 64 lanes' 16-byte pieces back to back, so rows are 128 B with no padding;
+// bank conflicts are avoided by permuting the 16 pieces of each 256-B row pair with the row-pair index (g' = g ^ (d & 15)):
+// the lane that owns LDS slot g' of pair d FETCHES piece g' ^ (d & 15) and the fragment reads apply the same involution.
+// Every ds_read_b128 lane group then touches 16 distinct 16-byte bank groups.
+//
+// The matrix instruction is fed weights as its row operand and pixels as its column operand, so a lane ends up with FOUR
+// CONSECUTIVE channels of ONE pixel per register quad: bias / residual / output move as 8-byte (SH) or 16-byte (fp32)
+// pieces instead of scalars.
+#include <stdlib.h>
+#include "omni_internal.h"
+#include "omni_sh.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
+                                             (int)(unsigned)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+
+// one LDS-DMA instruction: lane l's 16 bytes at buffer offset voff (+ soff, wave-uniform) land at lds + 16 l; offsets
+// outside the buffer deposit zeros.  (A plain function: the builtin is not accepted inside a kernel template's body by
+// the host pass, which then silently drops the kernel's launch stub.)
+__device__ __forceinline__ void dma16(rsrc_t rs, unsigned char* lds, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, soff, 0, 0);
+}
+
+// s_waitcnt vmcnt(N) with a compile-time count (the LDS-DMA pieces still allowed in flight)
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    static_assert(N >= 0 && N <= 24, "vmcnt out of the range spelled out below");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else static_assert(N < 0, "add the literal for this count");
+}
+
+struct ShConvArgs {
+    const void* src1; const void* src2;      // SH activations [M,H,W,C1], [M,H,W,C2] (src2 may be null)
+    const void* wt;                          // halfs [Cout][KH*KW*(C1+C2)/32][hi32|lo32], BN folded
+    const float* bias;                       // [Cout] or null
+    const void* res;                         // residual (SH), same shape as dst, or null
+    void* dst;                               // [M,Ho,Wo,Cout]: SH (dst_sh) or fp32 NHWC
+    int M, H, W, C1, C2, Ho, Wo, Cout;
+    int KH, KW, stride, pad, act;
+    int rows;                                // M*Ho*Wo
+    int dst_sh;
+    int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
+    int dbg;                                 // OMNI_CONV_DBG ablation bits (tuning only): 1 no MFMA, 2 no re-issue
+};
+
+template <int BM, int BN, int WM, int WN, int NST, int DBG = 0>
+__global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
+{
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
+    constexpr int APASS = BM / 32, BPASS = BN / 32, LPS = APASS + BPASS;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = a.Cout / BN;
+    const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x % ntn;
+    const int row0 = tile_m * BM, col0 = tile_n * BN;
+    const int G1 = a.C1 >> 5, G = (a.C1 + a.C2) >> 5;
+    const int ksteps = a.KH * a.KW * G;
+
+    // ---- DMA geometry: instruction j of a tile covers LDS row pairs 4j .. 4j+3; wave w issues j = w, w+4, ...  Lane i
+    // owns slot g' = i & 15 of pair d = 4j + (i >> 4), i.e. fetches piece g = g' ^ (d & 15) -> row 2d + (g >> 3), 16-byte
+    // piece g & 7.  (d & 15 does not depend on the pass, so the lane's piece is fixed and its row advances by 32 per pass.)
+    const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+    const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+    int pix[APASS];                                              // pixel index of the (possibly padded) window origin
+    unsigned vmask[APASS];                                       // bit (ky*KW+kx): tap inside the image
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int r = row0 + rl + 32 * i;
+        vmask[i] = 0; pix[i] = 0;
+        if (r < a.rows) {
+            const int hw = a.Ho * a.Wo;
+            const int m = r / hw, rem = r - m * hw;
+            const int oy = (rem / a.Wo) * a.stride - a.pad, ox = (rem % a.Wo) * a.stride - a.pad;
+            pix[i] = (m * a.H + oy) * a.W + ox;
+            unsigned vm = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    if (ky < a.KH && kx < a.KW && (unsigned)(oy + ky) < (unsigned)a.H && (unsigned)(ox + kx) < (unsigned)a.W)
+                        vm |= 1u << (ky * a.KW + kx);
+            vmask[i] = vm;
+        }
+    }
+    const rsrc_t rs1 = make_rsrc(a.src1, (size_t)a.M * a.H * a.W * a.C1 * 4);
+    const rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? (size_t)a.M * a.H * a.W * a.C2 * 4 : 0);
+    const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * ksteps * 128);
+    int wbase[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) wbase[i] = (col0 + rl + 32 * i) * ksteps * 128 + pc16;
+
+    int f_tap = 0, f_g = 0, f_ky = 0, f_kx = 0;                  // (tap, channel group) of the NEXT stage to issue
+    auto seek = [&](int ks) { f_tap = ks / G; f_g = ks - f_tap * G; f_ky = f_tap / a.KW; f_kx = f_tap - f_ky * a.KW; };
+    auto issue = [&](int ks, int slot) {
+        const bool first = f_g < G1;
+        const int cs4 = (first ? a.C1 : a.C2) * 4;               // pixel pitch in bytes of the source in use
+        const int soff = (f_ky * a.W + f_kx) * cs4 + (first ? f_g : f_g - G1) * 128 + pc16;
+        unsigned char* sb = lds + slot * STAGE + wave * 1024;
+        // (the range check of a raw buffer access sees the VGPR offset only and the origin of a padded window may lie
+        //  before the tensor: the tap term is folded into the VGPR offset)
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int off = ((vmask[i] >> f_tap) & 1u) ? pix[i] * cs4 + soff : (int)0x80000000;
+                dma16(rs1, sb + i * 4096, off, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int off = ((vmask[i] >> f_tap) & 1u) ? pix[i] * cs4 + soff : (int)0x80000000;
+                dma16(rs2, sb + i * 4096, off, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            dma16(rsw, sb + A_BYTES + i * 4096, wbase[i], ks * 128);
+        if (++f_g == G) { f_g = 0; ++f_tap; if (++f_kx == a.KW) { f_kx = 0; ++f_ky; } }
+    };
+
+    f16v acc[TM][TN], acc1[TM][TN];                              // acc = hi.hi, acc1 = hi.lo + lo.hi (scaled by 2^11)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { acc[i][j] = (f16v)(0.0f); acc1[i][j] = (f16v)(0.0f); }
+
+    // fragment offsets: row lane&31 of a 32-row tile, piece p = 2k + (lane>>5): k = 0,1 hi of the two 16-wide k chunks, 2,3 lo
+    int fo[4];
+    {
+        const int r = lane & 31, v = r >> 1, h = lane >> 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+    }
+
+    int ks_begin = 0, ks_end = ksteps;
+    if (a.splitk > 1) {
+        const int per = (ksteps + a.splitk - 1) / a.splitk;
+        ks_begin = blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
+    }
+    if (DBG & 8) ks_end = ks_begin;
+    seek(ks_begin);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (ks_begin + s < ks_end) issue(ks_begin + s, s);
+    int slot = 0, islot = NST - 1;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
+        else                       wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = ks + NST - 1 < ks_end && !(DBG & 2);
+        if (!(DBG & 16) && more) issue(ks + NST - 1, islot);
+        const unsigned char* sA = lds + slot * STAGE + wm * (BM / WM) * 128;
+        const unsigned char* sB = lds + slot * STAGE + A_BYTES + wn * (BN / WN) * 128;
+        if (DBG & 1) {
+            if ((DBG & 16) && more) issue(ks + NST - 1, islot);
+        } else {
+            h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[kc][i] = *reinterpret_cast<const h8v*>(sA + i * 4096 + fo[kc]);
+                    al[kc][i] = *reinterpret_cast<const h8v*>(sA + i * 4096 + fo[2 + kc]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[kc][j] = *reinterpret_cast<const h8v*>(sB + j * 4096 + fo[kc]);
+                    bl[kc][j] = *reinterpret_cast<const h8v*>(sB + j * 4096 + fo[2 + kc]);
+                }
+            }
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                if (DBG & 16) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);
+                    }
+                if ((DBG & 16) && kc == 0) {          // the next stage's DMA is issued under the first half's matrix work
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue(ks + NST - 1, islot);
+                }
+            }
+        }
+        if (++islot == NST) islot = 0;
+        if (++slot == NST) slot = 0;
+    }
+
+    if (DBG & 4) return;
+    // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = row0 + wm * (BM / WM) + i * 32 + (lane & 31);
+        if (r >= a.rows) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = col0 + wn * (BN / WN) + j * 32 + 8 * q + 4 * (lane >> 5);
+                f4v v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[i][j][4 * q + e], 4.8828125e-4f, acc[i][j][4 * q + e]);
+                const size_t o = (size_t)r * a.Cout + c;
+                if (a.splitk > 1) {
+                    *reinterpret_cast<f4v*>(a.ws + (size_t)blockIdx.y * a.rows * a.Cout + o) = v;
+                    continue;
+                }
+                if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + c);
+                if (a.res) {
+                    const unsigned char* rp = (const unsigned char*)a.res + sh_off(o);
+                    v += sh_join4(*reinterpret_cast<const h4v*>(rp), *reinterpret_cast<const h4v*>(rp + 64));
+                }
+                if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                }
+                if (a.dst_sh) {
+                    h4v hi, lo; sh_split4(v, hi, lo);
+                    unsigned char* dp = (unsigned char*)a.dst + sh_off(o);
+                    *reinterpret_cast<h4v*>(dp) = hi; *reinterpret_cast<h4v*>(dp + 64) = lo;
+                } else {
+                    *reinterpret_cast<f4v*>((float*)a.dst + o) = v;
+                }
+            }
+        }
+    }
+}
+
+// dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
+__global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                               const void* __restrict__ res, void* __restrict__ dst,
+                                                               size_t n4, int Cout, int splitk, size_t slab, int act, int dst_sh)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t o = i * 4;
+    f4v v = *reinterpret_cast<const f4v*>(ws + o);
+    for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f4v*>(ws + (size_t)s * slab + o);
+    if (bias) v += *reinterpret_cast<const f4v*>(bias + (o % Cout));
+    if (res) {
+        const unsigned char* rp = (const unsigned char*)res + sh_off(o);
+        v += sh_join4(*reinterpret_cast<const h4v*>(rp), *reinterpret_cast<const h4v*>(rp + 64));
+    }
+    if (act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (act == OMNI_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (dst_sh) {
+        h4v hi, lo; sh_split4(v, hi, lo);
+        unsigned char* dp = (unsigned char*)dst + sh_off(o);
+        *reinterpret_cast<h4v*>(dp) = hi; *reinterpret_cast<h4v*>(dp + 64) = lo;
+    } else {
+        *reinterpret_cast<f4v*>((float*)dst + o) = v;
+    }
+}
+
+// fp32 NHWC <-> SH (4 channels per thread)
+__global__ __launch_bounds__(256) void sh_from_f32_kernel(const float* __restrict__ src, void* __restrict__ dst, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    h4v hi, lo; sh_split4(*reinterpret_cast<const f4v*>(src + i * 4), hi, lo);
+    unsigned char* dp = (unsigned char*)dst + sh_off(i * 4);
+    *reinterpret_cast<h4v*>(dp) = hi; *reinterpret_cast<h4v*>(dp + 64) = lo;
+}
+__global__ __launch_bounds__(256) void sh_to_f32_kernel(const void* __restrict__ src, float* __restrict__ dst, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const unsigned char* sp = (const unsigned char*)src + sh_off(i * 4);
+    *reinterpret_cast<f4v*>(dst + i * 4) = sh_join4(*reinterpret_cast<const h4v*>(sp), *reinterpret_cast<const h4v*>(sp + 64));
+}
+
+template <int BM, int BN, int WM, int WN, int NST, int DBG = 0>
+void launch_sh(const ShConvArgs& a, hipStream_t s)
+{
+    const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
+    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, DBG>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+}
+}  // namespace
+
+// out[M,Ho,Wo,Cout] = act(conv(src1 ++ src2, wt16) + bias + res) with SH activations (see the file header).
+// src1/src2/res: SH tensors; dst: SH when dst_sh != 0, else fp32 NHWC; wt16 as for omni_conv2d_nhwc_f16x3_ws.
+// Requirements: C1, C2, Cout multiples of 32, kernels up to 3x3.  split-K as in omni_conv2d_nhwc_f32_ws.
+extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
+                                       const void* res, void* dst, int dst_sh, int M, int H, int W, int C1, int C2, int Cout,
+                                       int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                       omni_stream_t stream)
+{
+    if (!src1 || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: null pointer");
+    if (C1 <= 0 || C1 % 32 || C2 < 0 || C2 % 32 || Cout <= 0 || Cout % 32 || (C2 > 0 && !src2))
+        OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: channels must be multiples of 32");
+    if (M <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || KH > 3 || KW > 3 || stride <= 0 || pad < 0)
+        OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: bad shape (kernels up to 3x3)");
+    ShConvArgs a;
+    a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh;
+    a.M = M; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
+    a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
+    const long long rows = (long long)M * a.Ho * a.Wo;
+    if (rows <= 0 || rows >= (1ll << 31) || (long long)M * H * W >= (1ll << 31))
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv2d_sh: too many pixels for 32-bit row indices");
+    a.rows = (int)rows;
+    const int ksteps = KH * KW * ((C1 + C2) / 32);
+    if ((long long)M * H * W * (C1 > C2 ? C1 : C2) * 4 >= (1ll << 31) || (long long)Cout * ksteps * 128 >= (1ll << 31))
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv2d_sh: an operand of 2 GiB or more (32-bit buffer offsets)");
+    int S = splitk;
+    if (S > ksteps) S = ksteps;
+    if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
+        OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
+    a.splitk = S > 1 ? S : 1; a.ws = ws;
+    { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
+    hipStream_t s = (hipStream_t)stream;
+    // tile: results do not depend on it (every output element is the same k-ordered chain), so it is a pure tuning choice
+    int tile = 0;                                                  // 0: 64x64, 1: 128x64, 2: 128x128
+    { const char* e = getenv("OMNI_CONV_SH_TILE"); if (e) tile = atoi(e); }
+    if (Cout % 64 != 0) {
+        if (tile == 1) launch_sh<256, 32, 4, 1, 3>(a, s);
+        else           launch_sh<128, 32, 4, 1, 4>(a, s);
+    } else {
+        if (tile == 2 && Cout % 128 != 0) tile = 1;
+        switch (tile) {
+            case 2: launch_sh<128, 128, 2, 2, 3>(a, s); break;
+            case 1: launch_sh<128, 64, 2, 2, 3>(a, s); break;
+            case 3: launch_sh<64, 64, 2, 2, 4>(a, s); break;
+            case 11: launch_sh<64, 64, 2, 2, 3, 1>(a, s); break;
+            case 12: launch_sh<64, 64, 2, 2, 3, 2>(a, s); break;
+            case 13: launch_sh<64, 64, 2, 2, 3, 3>(a, s); break;
+            case 17: launch_sh<64, 64, 2, 2, 3, 7>(a, s); break;
+            case 21: launch_sh<64, 64, 2, 2, 3, 11>(a, s); break;
+            case 25: launch_sh<64, 64, 2, 2, 3, 15>(a, s); break;
+            case 31: launch_sh<128, 64, 2, 2, 3, 16>(a, s); break;
+            case 32: launch_sh<128, 128, 2, 2, 3, 16>(a, s); break;
+            case 33: launch_sh<64, 64, 2, 2, 4, 16>(a, s); break;
+            case 40: launch_sh<64, 64, 2, 2, 3>(a, s); break;
+            default: launch_sh<64, 64, 2, 2, 3, 16>(a, s); break;
+        }
+    }
+    OMNI_HIP(hipGetLastError());
+    if (a.splitk > 1) {
+        const size_t n4 = (size_t)rows * Cout / 4;
+        hipLaunchKernelGGL(sh_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, bias, res, dst,
+                           n4, Cout, a.splitk, (size_t)rows * Cout, act, dst_sh);
+        OMNI_HIP(hipGetLastError());
+    }
+    return OMNI_OK;
+}
+
+// layout conversions (n = number of elements, a multiple of 32 channels per pixel)
+extern "C" int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream)
+{
+    if (!src || !dst || n % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_sh_from_f32: null pointer or n % 32 != 0");
+    if (n == 0) return OMNI_OK;
+    hipLaunchKernelGGL(sh_from_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+extern "C" int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream)
+{
+    if (!src || !dst || n % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_sh_to_f32: null pointer or n % 32 != 0");
+    if (n == 0) return OMNI_OK;
+    hipLaunchKernelGGL(sh_to_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

@@ -42,3 +42,27 @@ extern "C" int omni_debug_fill(float* p, size_t n_per_plane, int planes, int mod
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
+
+// LDS-DMA through a buffer descriptor: what lands in LDS for a lane whose offset is out of range?
+namespace {
+typedef __attribute__((address_space(3))) void* lptr_t;
+__global__ __launch_bounds__(64) void dma_probe_kernel(const float* src, unsigned bytes, const int* offs, float* out)
+{
+    __shared__ __attribute__((aligned(16))) float buf[256];
+    const int lane = threadIdx.x;
+    for (int i = 0; i < 4; ++i) buf[lane * 4 + i] = -7.0f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)buf, 16, offs[lane], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) out[lane * 4 + i] = buf[lane * 4 + i];
+}
+}  // namespace
+
+extern "C" int omni_debug_dma_probe(const float* src, unsigned bytes, const int* offs, float* out, omni_stream_t stream)
+{
+    hipLaunchKernelGGL(dma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, bytes, offs, out);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

@@ -10,6 +10,7 @@
 //   heads           pred (ReLU) / weight_pred (sigmoid) 3x3 32->1     :223-224,304-307
 //   mlp_points      1x1 conv 3->16->64 (+BN+ReLU) of xyz (* depth)    spherical_model_iterative.py:290-305,319,387-393
 #include "omni_internal.h"
+#include "omni_sh.h"
 
 namespace {
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -18,8 +19,9 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // block: 8x8 output pixels x 64 channels.  Input patch (21x21x3, zero padded) and the whole folded
 // filter bank [147][64] live in LDS; thread = (pixel t&63, 16 channels t>>6): the four 16-byte weight
 // reads per tap are wave-uniform addresses (LDS broadcast).
+template <bool SH>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ src, const float* __restrict__ wt,
-                                                   const float* __restrict__ bias, float* __restrict__ dst,
+                                                   const float* __restrict__ bias, void* __restrict__ dst,
                                                    int M, int P, int Po)
 {
     __shared__ __attribute__((aligned(16))) float wl[147 * 64];
@@ -56,17 +58,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ src
                     acc[4 * j4 + 2] = fmaf(x, wv.z, acc[4 * j4 + 2]); acc[4 * j4 + 3] = fmaf(x, wv.w, acc[4 * j4 + 3]);
                 }
             }
-    float* o = dst + (((size_t)m * Po + oy0 + py) * Po + ox0 + px) * 64 + cg;
+    const size_t o = (((size_t)m * Po + oy0 + py) * Po + ox0 + px) * 64 + cg;
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
         f4v v;
         v.x = fmaxf(acc[4 * j4], 0.f); v.y = fmaxf(acc[4 * j4 + 1], 0.f); v.z = fmaxf(acc[4 * j4 + 2], 0.f); v.w = fmaxf(acc[4 * j4 + 3], 0.f);
-        *reinterpret_cast<f4v*>(o + 4 * j4) = v;
+        act_store4<SH>(dst, o + 4 * j4, v);
     }
 }
 
 // ------------------------------------------------------------------ maxpool 3x3 s2 p1 (NHWC, 4 channels per thread)
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <bool SH>
+__global__ __launch_bounds__(256) void maxpool_kernel(const void* __restrict__ src, void* __restrict__ dst,
                                                       int M, int H, int W, int C, int Ho, int Wo)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -84,15 +87,16 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
         for (int kx = 0; kx < 3; ++kx) {
             const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
             if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                const f4v v = *reinterpret_cast<const f4v*>(src + (((size_t)m * H + iy) * W + ix) * C + c);
+                const f4v v = act_load4<SH>(src, (((size_t)m * H + iy) * W + ix) * C + c);
                 best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
             }
         }
-    *reinterpret_cast<f4v*>(dst + (((size_t)m * Ho + oy) * Wo + ox) * C + c) = best;
+    act_store4<SH>(dst, (((size_t)m * Ho + oy) * Wo + ox) * C + c, best);
 }
 
 // ------------------------------------------------------------------ bilinear upsample, align_corners=False (ATen upsample_bilinear2d)
-__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <bool SH>
+__global__ __launch_bounds__(256) void upsample_kernel(const void* __restrict__ src, void* __restrict__ dst,
                                                        int M, int H, int W, int C, int Ho, int Wo, float sy, float sx)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -108,17 +112,17 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
-    const float* b = src + (size_t)m * H * W * C + c;
-    const f4v v00 = *reinterpret_cast<const f4v*>(b + ((size_t)y0 * W + x0) * C);
-    const f4v v01 = *reinterpret_cast<const f4v*>(b + ((size_t)y0 * W + x1) * C);
-    const f4v v10 = *reinterpret_cast<const f4v*>(b + ((size_t)y1 * W + x0) * C);
-    const f4v v11 = *reinterpret_cast<const f4v*>(b + ((size_t)y1 * W + x1) * C);
+    const size_t b = (size_t)m * H * W * C + c;
+    const f4v v00 = act_load4<SH>(src, b + ((size_t)y0 * W + x0) * C);
+    const f4v v01 = act_load4<SH>(src, b + ((size_t)y0 * W + x1) * C);
+    const f4v v10 = act_load4<SH>(src, b + ((size_t)y1 * W + x0) * C);
+    const f4v v11 = act_load4<SH>(src, b + ((size_t)y1 * W + x1) * C);
     f4v o;
     o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
     o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
     o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
     o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-    *reinterpret_cast<f4v*>(dst + (((size_t)m * Ho + oy) * Wo + ox) * C + c) = o;
+    act_store4<SH>(dst, (((size_t)m * Ho + oy) * Wo + ox) * C + c, o);
 }
 
 // x[m][hw][c] += y[m][c]            (token bias on layer4)
@@ -139,6 +143,23 @@ __global__ __launch_bounds__(256) void add_period_kernel(float* __restrict__ x, 
 }
 
 // d[m][hw][c32] -> tok[m][c*HW + hw] + pos[(m % N)][.]      (reshape(bs,-1,N).transpose(1,2) of :264, + pos_emb :181)
+// the same two adds on an SH tensor x (y stays fp32), four channels per thread
+__global__ __launch_bounds__(256) void add_hw_sh_kernel(void* __restrict__ x, const float* __restrict__ y, size_t total4, int HW, int C)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const size_t e = i * 4;
+    const int c = (int)(e % C);
+    const size_t m = e / ((size_t)HW * C);
+    act_store4<true>(x, e, act_load4<true>(x, e) + *reinterpret_cast<const f4v*>(y + m * C + c));
+}
+__global__ __launch_bounds__(256) void add_period_sh_kernel(void* __restrict__ x, const float* __restrict__ y, size_t total4, size_t period)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const size_t e = i * 4;
+    act_store4<true>(x, e, act_load4<true>(x, e) + *reinterpret_cast<const f4v*>(y + e % period));
+}
 __global__ __launch_bounds__(256) void token_pack_kernel(const float* __restrict__ d, const float* __restrict__ pos,
                                                          float* __restrict__ tok, int M, int N, int HW, int C)
 {
@@ -298,18 +319,18 @@ int omni_stem_f32(const float* src, const float* wt, const float* bias, float* d
 {
     if (P % 16) OMNI_FAIL(OMNI_ERR_INVALID, "omni_stem: patch size must be a multiple of 16");
     const int Po = P / 2;
-    hipLaunchKernelGGL(stem_kernel, dim3(M * (Po / 8) * (Po / 8)), dim3(256), 0, S_, src, wt, bias, dst, M, P, Po);
+    hipLaunchKernelGGL(stem_kernel<false>, dim3(M * (Po / 8) * (Po / 8)), dim3(256), 0, S_, src, wt, bias, (void*)dst, M, P, Po);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_maxpool3x3s2_f32(const float* src, float* dst, int M, int H, int W, int C, omni_stream_t stream)
 {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, src, dst, M, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_kernel<false>, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, (const void*)src, (void*)dst, M, H, W, C, Ho, Wo);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_upsample_bilinear_f32(const float* src, float* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream)
 {
-    hipLaunchKernelGGL(upsample_kernel, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, src, dst, M, H, W, C, Ho, Wo,
+    hipLaunchKernelGGL(upsample_kernel<false>, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, (const void*)src, (void*)dst, M, H, W, C, Ho, Wo,
                        (float)H / (float)Ho, (float)W / (float)Wo);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
@@ -322,6 +343,41 @@ int omni_add_hw_f32(float* x, const float* y, int M, int HW, int C, omni_stream_
 int omni_add_period_f32(float* x, const float* y, size_t total, size_t period, omni_stream_t stream)
 {
     hipLaunchKernelGGL(add_period_kernel, dim3(nblk(total)), dim3(256), 0, S_, x, y, total, period);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
+// ---- the same operators on split-half (SH) activations (omni_sh.h); C % 32 == 0
+int omni_stem_sh(const float* src, const float* wt, const float* bias, void* dst, int M, int P, omni_stream_t stream)
+{
+    if (P % 16) OMNI_FAIL(OMNI_ERR_INVALID, "omni_stem: patch size must be a multiple of 16");
+    const int Po = P / 2;
+    hipLaunchKernelGGL(stem_kernel<true>, dim3(M * (Po / 8) * (Po / 8)), dim3(256), 0, S_, src, wt, bias, dst, M, P, Po);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
+int omni_maxpool3x3s2_sh(const void* src, void* dst, int M, int H, int W, int C, omni_stream_t stream)
+{
+    if (C % 32) OMNI_FAIL(OMNI_ERR_INVALID, "SH tensors need C % 32 == 0");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_kernel<true>, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, src, dst, M, H, W, C, Ho, Wo);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
+int omni_upsample_bilinear_sh(const void* src, void* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream)
+{
+    if (C % 32) OMNI_FAIL(OMNI_ERR_INVALID, "SH tensors need C % 32 == 0");
+    hipLaunchKernelGGL(upsample_kernel<true>, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, src, dst, M, H, W, C, Ho, Wo,
+                       (float)H / (float)Ho, (float)W / (float)Wo);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
+int omni_add_hw_sh(void* x, const float* y, int M, int HW, int C, omni_stream_t stream)
+{
+    if (C % 32) OMNI_FAIL(OMNI_ERR_INVALID, "SH tensors need C % 32 == 0");
+    const size_t total4 = (size_t)M * HW * C / 4;
+    hipLaunchKernelGGL(add_hw_sh_kernel, dim3(nblk(total4)), dim3(256), 0, S_, x, y, total4, HW, C);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
+int omni_add_period_sh(void* x, const float* y, size_t total, size_t period, omni_stream_t stream)
+{
+    if (total % 32 || period % 32) OMNI_FAIL(OMNI_ERR_INVALID, "SH tensors need C % 32 == 0");
+    hipLaunchKernelGGL(add_period_sh_kernel, dim3(nblk(total / 4)), dim3(256), 0, S_, x, y, total / 4, period);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream)

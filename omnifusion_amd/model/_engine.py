@@ -49,10 +49,15 @@ class Engine:
             raise ValueError("square patches only")
         self.w = None          # packed weights (device tensors)
         self.device = None
-        # "f16x3": conv products on the fp16 matrix cores with split operands (fp32-class accuracy, 3/16 of the MFMA time);
-        # "fp32": the exact fp32 MFMA everywhere.  OMNI_NET_PRECISION overrides.
+        # "f16x3": conv products on the fp16 matrix cores with split operands (fp32-class accuracy, 3/16 of the MFMA time),
+        # activations between the convolutions in the split-half layout; "fp32": the exact fp32 MFMA, fp32 NHWC activations.
+        # OMNI_NET_PRECISION overrides.
         import os
         self.precision = os.environ.get("OMNI_NET_PRECISION", "f16x3")
+
+    @property
+    def sh(self):
+        return self.precision == "f16x3"
 
     # ------------------------------------------------------------------ packing
     @staticmethod
@@ -94,6 +99,7 @@ class Engine:
             convbn(name, name + ".conv", name + ".bn")
         down = "down1" if self.iterative else "down"
         W["down.w"] = f(sd[down + ".weight"].reshape(32, 512)); W["down.b"] = f(sd[down + ".bias"])
+        W["down.w16"] = split_weights_f16x3(sd[down + ".weight"].reshape(32, 512)).to(dev)
         W["pos"] = f(sd["transformer.pos_emb"].reshape(self.npatches, 512))
         for i in range(6):
             p = f"transformer.layer.{i}"
@@ -128,20 +134,21 @@ class Engine:
         self.w, self.device = W, dev
 
     # ------------------------------------------------------------------ operator shims
-    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True):
+    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True, out_f32=False):
+        """One convolution (+ folded BN, bias, residual, activation).  In the f16x3 mode the activations x, x2, res and
+        the result are split-half (SH) tensors (csrc/omni_sh.h) unless out_f32 asks for a plain fp32 NHWC result."""
         lib = _lib.load()
         Ho = (H + 2 * pad - k) // stride + 1
         Wo = (Wd + 2 * pad - k) // stride + 1
         out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
-        if self.precision == "f16x3" and (key + ".w16") in self.w:
-            rc = lib.omni_conv2d_nhwc_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), _p(self.w[key + ".b"]) if bias else None,
-                                               _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws),
-                                               ctypes.c_size_t(nb), self._s)
+        b = _p(self.w[key + ".b"]) if bias else None
+        if self.sh:
+            rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), 0 if out_f32 else 1,
+                                             M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         else:
-            rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), _p(self.w[key + ".b"]) if bias else None,
-                                             _p(res), _p(out), M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws),
-                                             ctypes.c_size_t(nb), self._s)
+            rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), b, _p(res), _p(out), M, H, Wd, C1, C2, Cout,
+                                             k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "conv2d " + key)
         return out
 
@@ -184,7 +191,8 @@ class Engine:
 
     def _up(self, x, M, H, Wd, C, Ho, Wo):
         y = torch.empty((M, Ho, Wo, C), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().omni_upsample_bilinear_f32(_p(x), _p(y), M, H, Wd, C, Ho, Wo, self._s), "upsample")
+        fn = _lib.load().omni_upsample_bilinear_sh if self.sh else _lib.load().omni_upsample_bilinear_f32
+        _lib.check(fn(_p(x), _p(y), M, H, Wd, C, Ho, Wo, self._s), "upsample")
         return y
 
     # ------------------------------------------------------------------ network over the patch batch
@@ -200,9 +208,11 @@ class Engine:
         P2, P4, P8, P16, P32 = P // 2, P // 4, P // 8, P // 16, P // 32
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         conv1 = new(M, P2, P2, 64)
-        _lib.check(lib.omni_stem_f32(_p(patches), _p(self.w["stem.w"]), _p(self.w["stem.b"]), _p(conv1), M, P, self._s), "stem")
+        sh = self.sh                                                # activations between the convolutions: SH or fp32 NHWC
+        _lib.check((lib.omni_stem_sh if sh else lib.omni_stem_f32)(_p(patches), _p(self.w["stem.w"]), _p(self.w["stem.b"]),
+                                                                    _p(conv1), M, P, self._s), "stem")
         x = new(M, P4, P4, 64)
-        _lib.check(lib.omni_maxpool3x3s2_f32(_p(conv1), _p(x), M, P2, P2, 64, self._s), "maxpool")
+        _lib.check((lib.omni_maxpool3x3s2_sh if sh else lib.omni_maxpool3x3s2_f32)(_p(conv1), _p(x), M, P2, P2, 64, self._s), "maxpool")
         feats = {}
         cin, size = 64, P4
         for lname, nblk, stride in _LAYERS:
@@ -218,15 +228,15 @@ class Engine:
                 x = self._conv(y, p + ".c2", M, size, size, cout, cout, 3, 1, 1, ACT_RELU, res=ident)
                 cin = cout
             if lname == "layer1":                                   # layer1 + point_feat (:258)
-                _lib.check(lib.omni_add_period_f32(_p(x), _p(point_feat), ctypes.c_size_t(x.numel()),
-                                                   ctypes.c_size_t(point_feat.numel()), self._s), "add point_feat")
+                _lib.check((lib.omni_add_period_sh if sh else lib.omni_add_period_f32)(
+                    _p(x), _p(point_feat), ctypes.c_size_t(x.numel()), ctypes.c_size_t(point_feat.numel()), self._s), "add point_feat")
             feats[lname] = x
         layer1, layer2, layer3, layer4 = (feats[k] for k in ("layer1", "layer2", "layer3", "layer4"))
         # ---- transformer over the N tokens of each panorama (:263-268)
         if 32 * P32 * P32 != 512:
             raise RuntimeError(f"patch size {P}: token dim {32 * P32 * P32} != 512 — the reference network only exists at "
                                "patch size 128 (SURVEY.md finding 0.1)")
-        d = self._conv(layer4, "down", M, P32, P32, 512, 32, 1, 1, 0, ACT_NONE)
+        d = self._conv(layer4, "down", M, P32, P32, 512, 32, 1, 1, 0, ACT_NONE, out_f32=True)
         tok = new(M, 512)
         _lib.check(lib.omni_token_pack_f32(_p(d), _p(self.w["pos"]), _p(tok), M, N, P32 * P32, 32, self._s), "token_pack")
         for i in range(6):
@@ -241,7 +251,7 @@ class Engine:
             h = self._gemm(y, t + "mlp.fc1.weight", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU)
             tok = self._gemm(h, t + "mlp.fc2.weight", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
         tok = self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
-        _lib.check(lib.omni_add_hw_f32(_p(layer4), _p(tok), M, P32 * P32, 512, self._s), "token bias")
+        _lib.check((lib.omni_add_hw_sh if sh else lib.omni_add_hw_f32)(_p(layer4), _p(tok), M, P32 * P32, 512, self._s), "token bias")
         # ---- decoder (:270-302); torch.cat is the two-source form of the conv
         up = self._up(layer4, M, P32, P32, 512, P16, P16)
         x = self._conv(up, "de_conv0_0", M, P16, P16, 512, 256, 3, 1, 1, ACT_RELU)
@@ -256,7 +266,7 @@ class Engine:
         x = self._conv(up, "de_conv3_0", M, P2, P2, 64, 64, 3, 1, 1, ACT_RELU)
         x = self._conv(x, "de_conv3_1", M, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1, C2=64)
         up = self._up(x, M, P2, P2, 32, P, P)
-        x = self._conv(up, "de_conv4_0", M, P, P, 32, 32, 3, 1, 1, ACT_RELU)
+        x = self._conv(up, "de_conv4_0", M, P, P, 32, 32, 3, 1, 1, ACT_RELU, out_f32=True)
         a = new(bs, N, 1, P, P)
         c = new(bs, N, 1, P, P) if confidence else None
         _lib.check(lib.omni_heads_f32(_p(x), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]),

@@ -84,6 +84,81 @@ def test_conv2d_vs_torch(cfg):
                                            S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
         assert rc == 0, lib.omni_last_error()
         assert (o16.cpu().double() - ref).abs().max().item() < 3e-5, S
+    # the same arithmetic with split-half (SH) activations streamed into LDS by DMA; SH and fp32 outputs, every tile shape
+    import os
+    n32 = lambda t: ctypes.c_size_t(t.numel())
+    def to_sh(t):
+        if t is None:
+            return None
+        o = torch.empty_like(t)
+        assert lib.omni_sh_from_f32(_p(t), _p(o), n32(t), _stream()) == 0
+        return o
+    S1, S2, SR = to_sh(X1), to_sh(X2), to_sh(R)
+    back = torch.empty_like(X1)
+    assert lib.omni_sh_to_f32(_p(S1), _p(back), n32(X1), _stream()) == 0
+    assert (back - X1).abs().max().item() <= 2.0 ** -22 * X1.abs().max().item()
+    try:
+        for tile in ("0", "1", "2", "3"):
+            os.environ["OMNI_CONV_SH_TILE"] = tile
+            for S in (1, min(3, ksteps)):
+                for dst_sh in (0, 1):
+                    ws = torch.empty(S * out.numel(), device=DEV)
+                    osh = torch.empty_like(out)
+                    rc = lib.omni_conv2d_sh_f16x3_ws(_p(S1), _p(S2), _p(W16), _p(B), _p(SR), _p(osh), dst_sh, M, H, W, C1, C2, Cout,
+                                                     k, k, s, pad, act, S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+                    assert rc == 0, lib.omni_last_error()
+                    if dst_sh:
+                        o32 = torch.empty_like(out)
+                        assert lib.omni_sh_to_f32(_p(osh), _p(o32), n32(out), _stream()) == 0
+                        osh = o32
+                    assert (osh.cpu().double() - ref).abs().max().item() < 3e-5, (tile, S, dst_sh)
+    finally:
+        os.environ.pop("OMNI_CONV_SH_TILE", None)
+
+
+def test_sh_elementwise_ops_match_f32():
+    """The split-half (SH) variants of stem / maxpool / upsample / broadcast adds equal the fp32 operators up to the
+    22-bit split (x = hi + lo*2^-11) of their inputs and outputs."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(3)
+    n = lambda t: ctypes.c_size_t(t.numel())
+    def to_sh(t):
+        o = torch.empty_like(t); assert lib.omni_sh_from_f32(_p(t), _p(o), n(t), _stream()) == 0; return o
+    def from_sh(t):
+        o = torch.empty_like(t); assert lib.omni_sh_to_f32(_p(t), _p(o), n(t), _stream()) == 0; return o
+    close = lambda a, b: (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+    # stem
+    M, P = 3, 32
+    src = torch.rand(M, 3, P, P, generator=g).to(DEV)
+    wt = (torch.randn(147, 64, generator=g) / 12).to(DEV); b = torch.randn(64, generator=g).to(DEV)
+    o32 = torch.empty(M, P // 2, P // 2, 64, device=DEV); osh = torch.empty_like(o32)
+    assert lib.omni_stem_f32(_p(src), _p(wt), _p(b), _p(o32), M, P, _stream()) == 0
+    assert lib.omni_stem_sh(_p(src), _p(wt), _p(b), _p(osh), M, P, _stream()) == 0
+    assert close(from_sh(osh), o32)
+    # maxpool / upsample on a 64-channel tensor
+    x = torch.randn(3, 10, 12, 64, generator=g).to(DEV); xs = to_sh(x)
+    mp32 = torch.empty(3, 5, 6, 64, device=DEV); mpsh = torch.empty_like(mp32)
+    assert lib.omni_maxpool3x3s2_f32(_p(x), _p(mp32), 3, 10, 12, 64, _stream()) == 0
+    assert lib.omni_maxpool3x3s2_sh(_p(xs), _p(mpsh), 3, 10, 12, 64, _stream()) == 0
+    assert close(from_sh(mpsh), mp32)
+    up32 = torch.empty(3, 20, 24, 64, device=DEV); upsh = torch.empty_like(up32)
+    assert lib.omni_upsample_bilinear_f32(_p(x), _p(up32), 3, 10, 12, 64, 20, 24, _stream()) == 0
+    assert lib.omni_upsample_bilinear_sh(_p(xs), _p(upsh), 3, 10, 12, 64, 20, 24, _stream()) == 0
+    assert close(from_sh(upsh), up32)
+    # broadcast adds
+    y = torch.randn(3, 64, generator=g).to(DEV)
+    a32, ash = x.clone(), to_sh(x)
+    assert lib.omni_add_hw_f32(_p(a32), _p(y), 3, 120, 64, _stream()) == 0
+    assert lib.omni_add_hw_sh(_p(ash), _p(y), 3, 120, 64, _stream()) == 0
+    assert close(from_sh(ash), a32)
+    per = torch.randn(10 * 12 * 64, generator=g).to(DEV)
+    a32, ash = x.clone(), to_sh(x)
+    assert lib.omni_add_period_f32(_p(a32), _p(per), n(x), n(per), _stream()) == 0
+    assert lib.omni_add_period_sh(_p(ash), _p(per), n(x), n(per), _stream()) == 0
+    assert close(from_sh(ash), a32)
+    # tiny magnitudes: |x| < 2^-14 keeps hi = 0 and the value in lo
+    t = (torch.randn(64, generator=g) * 1e-6).to(DEV)
+    assert (from_sh(to_sh(t)) - t).abs().max().item() < 2.0 ** -25
 
 
 def test_small_ops_vs_torch():

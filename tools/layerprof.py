@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""Print the kernel sequence of the LAST forward in a rocprofv3 kernel trace (csv), with durations.
+usage: python tools/layerprof.py gpurun_out/prof_x/**/x_kernel_trace.csv"""
+import csv, sys, re, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "e2p_lds_kernel" in r["Kernel_Name"]]
+# last forward = from the last e2p at P=128 (grid differs from P=256) .. next p2e kernel
+start = None
+for i in reversed(idx):
+    start = i
+    nxt = [j for j in range(i + 1, len(rows)) if "p2e_kernel" in rows[j]["Kernel_Name"]]
+    if nxt and nxt[0] - i > 50:
+        end = nxt[0]
+        break
+tot = collections.Counter()
+for r in rows[start:end + 1]:
+    n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])[:70]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot[n] += d
+    if len(sys.argv) > 2:
+        print(f"{n:72s} grid={r['Grid_Size_X']:>9s} {d:8.1f}")
+print("---- totals (us)")
+for n, d in tot.most_common():
+    print(f"{n:72s} {d:8.1f}")
+print("sum", sum(tot.values()))

@@ -275,6 +275,160 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------ 3x3 stride-1 convolution with halo-tile reuse (SH)
+// The tile kernel above fetches every input pixel group once per tap (9x the input through L2 -> LDS), which is what
+// bounds the wide, shallow decoder layers (de_conv3_x, de_conv4_0: 64^2 / 128^2 images, 32-128 channels).  Here a block
+// owns a 4x32 pixel tile of ONE image and BN output channels; per 32-channel group it DMAs the 6x34 halo patch into LDS
+// ONCE (pixel-major 128-B rows, same pair swizzle, out-of-image pixels arrive as zeros) and serves the nine taps from it:
+// wave w owns image row y0+w (32 pixels = one MFMA column tile), its pixel fragment for tap (ky,kx) is the same LDS image
+// shifted by ky rows and kx pixels.  The weights arrive one kernel row (3 taps) at a time through a double buffer: the
+// next row's DMA is in flight under the 18*BN/32 MFMAs of the current one.  Requires W % 32 == 0, H % 4 == 0.
+constexpr int HT_H = 4, HT_W = 32, HPW = HT_W + 2, HPX = (HT_H + 2) * HPW;      // 204 halo pixels
+constexpr int HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;       // 26 DMA instructions, 26 KiB
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
+{
+    constexpr int TN = BN / 32;
+    constexpr int APASS = (HA_INSTR + 3) / 4, BROWS = 3 * BN, BPASS = BROWS / 32, B_BYTES = BROWS * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[HA_BYTES + 2 * B_BYTES];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / HT_H;
+    int bid = blockIdx.x;
+    const int tile_n = bid % ntn; bid /= ntn;
+    const int tx = bid % tw; bid /= tw;
+    const int ty = bid % th; const int m = bid / th;
+    const int y0 = ty * HT_H, x0 = tx * HT_W, col0 = tile_n * BN;
+    const int G1 = a.C1 >> 5, G = (a.C1 + a.C2) >> 5, ksteps = 9 * G;
+
+    // DMA geometry (as in conv_sh_kernel): lane -> row rl + 32*pass of the region, 16-byte piece pc16/16
+    const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+    const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+    int apix[APASS];                                              // image pixel index of halo pixel rl + 32*i, or -1
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int p = rl + 32 * i;
+        const int hy = p / HPW, hx = p - hy * HPW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        apix[i] = (p < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (m * a.H + iy) * a.W + ix : -1;
+    }
+    int wbase[BPASS];                                             // weight row (kx, co) = row rl + 32*i of a kernel-row stage
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int r = rl + 32 * i, kx = r / BN, co = r - kx * BN;
+        wbase[i] = ((col0 + co) * ksteps + kx * G) * 128 + pc16;
+    }
+    const rsrc_t rs1 = make_rsrc(a.src1, (size_t)a.M * a.H * a.W * a.C1 * 4);
+    const rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? (size_t)a.M * a.H * a.W * a.C2 * 4 : 0);
+    const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * ksteps * 128);
+
+    auto issue_a = [&](int g) {
+        const bool first = g < G1;
+        const int cs4 = (first ? a.C1 : a.C2) * 4;
+        const int soff = (first ? g : g - G1) * 128 + pc16;
+        unsigned char* sb = lds + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            if (wave + 4 * i < HA_INSTR) {
+                const int off = apix[i] >= 0 ? apix[i] * cs4 + soff : (int)0x80000000;
+                if (first) dma16(rs1, sb + i * 4096, off, 0);
+                else       dma16(rs2, sb + i * 4096, off, 0);
+            }
+        }
+    };
+    auto issue_b = [&](int g, int ky, int buf) {
+        unsigned char* sb = lds + HA_BYTES + buf * B_BYTES + wave * 1024;
+        const int soff = (ky * 3 * G + g) * 128;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + i * 4096, wbase[i], soff);
+    };
+
+    // pixel fragment offsets of the nine taps: halo pixel p = (wave+ky)*34 + (lane&31) + kx, row pair d = p >> 1,
+    // first piece (hi, k chunk 0) at d*256 + 16*((8*(p&1) + (lane>>5)) ^ (d&15)); the other three pieces are that offset
+    // XOR 32 / 64 / 96 (k chunk 1, lo chunk 0, lo chunk 1)
+    int ao[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int p = (wave + ky) * HPW + (lane & 31) + kx, d = p >> 1;
+            ao[ky * 3 + kx] = d * 256 + ((((p & 1) * 8 + (lane >> 5)) ^ (d & 15)) * 16);
+        }
+    int fo[4];                                                    // weight fragment offsets (32 consecutive rows)
+    {
+        const int r = lane & 31, v = r >> 1, h = lane >> 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+    }
+
+    f16v acc[TN], acc1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
+
+    issue_a(0);
+    issue_b(0, 0, 0);
+    int buf = 0;
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            wait_vm<0>();                                         // halo (ky == 0) and this kernel row's weights have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ky < 2) issue_b(g, ky + 1, buf ^ 1);              // next weights under this row's matrix work
+            else if (g + 1 < G) issue_b(g + 1, 0, buf ^ 1);
+            const unsigned char* sB = lds + HA_BYTES + buf * B_BYTES;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int a0 = ao[ky * 3 + kx];
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const h8v ah = *reinterpret_cast<const h8v*>(lds + (a0 ^ (kc * 32)));
+                    const h8v al = *reinterpret_cast<const h8v*>(lds + (a0 ^ (64 + kc * 32)));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned char* bp = sB + (kx * BN + j * 32) * 128;
+                        const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
+                        const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+        if (g + 1 < G) {                                          // everybody is done with this group's halo: fetch the next
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_a(g + 1);
+        }
+    }
+
+    // ---- epilogue (as conv_sh_kernel): column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
+    const int r = (m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = col0 + j * 32 + 8 * q + 4 * (lane >> 5);
+            f4v v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
+            const size_t o = (size_t)r * a.Cout + c;
+            if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + c);
+            if (a.res) v += act_load4<true>(a.res, o);
+            if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            }
+            if (a.dst_sh) act_store4<true>(a.dst, o, v);
+            else          act_store4<false>(a.dst, o, v);
+        }
+    }
+}
+
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
 __global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                const void* __restrict__ res, void* __restrict__ dst,
@@ -361,6 +515,13 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     a.splitk = S > 1 ? S : 1; a.ws = ws;
     { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
     hipStream_t s = (hipStream_t)stream;
+    if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % HT_H == 0 && !getenv("OMNI_CONV_NOHALO")) {
+        const int grid = M * (H / HT_H) * (W / HT_W);
+        if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
+        else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
+    }
     // tile: results do not depend on it (every output element is the same k-ordered chain), so it is a pure tuning choice
     int tile = 0;                                                  // 0: 64x64, 1: 128x64, 2: 128x128
     { const char* e = getenv("OMNI_CONV_SH_TILE"); if (e) tile = atoi(e); }

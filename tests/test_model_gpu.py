@@ -37,6 +37,8 @@ def _stream():
     (36, 4, 4, 512, 0, 512, 3, 1, 1, 1, True),
     (18, 1, 1, 512, 0, 2048, 1, 1, 0, 2, False),
     (40, 64, 64, 32, 0, 32, 3, 1, 1, 1, False),
+    (3, 32, 64, 64, 64, 64, 3, 1, 1, 1, True),
+    (2, 8, 32, 32, 96, 128, 3, 1, 1, 0, False),
 ])
 def test_conv2d_vs_torch(cfg):
     """omni_conv2d_nhwc_f32 (plain and split-K) and omni_conv2d_sh_f16x3 against a plain PyTorch fp32 reference of the same op (CPU, float64 accumulate)."""

@@ -16,7 +16,9 @@ Workload notes (DESIGN.md "Measurement"):
     at 512x1024 ERP, nrows = 4 (18 patches), P = 128;
   * the resample pair named by the metric (18 x 256^2 patches, equi2pers C=3 + pers2equi C=1) is
     timed in the same run and reported as `roofline_resample` (HBM-bound);
-  * `roofline` is the dominant part of the step: the conv/GEMM network on the fp32 matrix cores.
+  * `roofline` is the dominant part of the step: the conv/GEMM network on the matrix cores.  In the default f16x3 mode
+    every product block is THREE fp16 MFMAs on hi/lo half pairs (fp32-class accuracy), so the ceiling for ALGORITHMIC
+    flops is the fp16 dense peak / 3 = 833 TFLOP/s; `achieved` is algorithmic (fp32-equivalent) TFLOP/s against that.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,7 +34,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3-6.9 TB/s achievable)
-MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector peak)
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector peak): the OMNI_NET_PRECISION=fp32 mode
+MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md); the f16x3 mode issues 3 of them per product
 ERP_H, ERP_W, NROWS, NPATCH, FOV = 512, 1024, 4, 18, (80.0, 80.0)
 NET_GFLOP_PER_PANO = 71.3      # 2 x 35.66 GMAC at P=128, N=18 (probed with forward hooks)
 
@@ -127,6 +130,8 @@ def main():
     sec = lambda i: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) * 1e-3
     t_e2p, t_net, t_p2e = sec(0), sec(1), sec(2)
     tflops = NET_GFLOP_PER_PANO * B / t_net / 1e3
+    f16x3 = eng.precision == "f16x3"
+    peak = MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS
 
     # ---- the resample pair at the metric's patch size (18 x 256^2), same run, HIP events on the launch stream
     P = 256
@@ -154,17 +159,22 @@ def main():
         "value": world * B * args.steps / dt, "unit": "panoramas/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f16x3 (fp16 hi/lo pairs, fp32 accumulate: fp32-class)" if f16x3 else "f32", "data": "synthetic",
         "config": {"workload": f"cfg2/cfg4 shard: {B} panoramas/GPU/step, 512x1024 ERP, fov 80, nrows 4 (18 patches); full "
                                "single-pass spherical_fusion forward (confidence=True) at patch size 128 — the only size the "
                                "reference network exists at (SURVEY 0.1); random-init weights (seed 42); inputs resident in HBM; "
                                "resample pair at 18x256^2 reported in roofline_resample",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}"},
         "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3},
-        "roofline": {"bound": "mfma", "kernel": "network section (conv_igemm_f32_kernel<...> dominant; includes stem/pool/"
-                                                "upsample/LN/attention/heads launches)",
-                     "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9},
+        "roofline": {"bound": "mfma",
+                     "kernel": ("network section (conv_sh_kernel / conv3x3_halo_sh_kernel dominant" if f16x3 else
+                                "network section (conv_igemm_f32_kernel<...> dominant") + "; includes the stem/pool/upsample/LN/"
+                               "attention/heads launches)",
+                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+                     "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9,
+                     "note": ("algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product: "
+                              f"{3 * tflops:.0f} of {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s fp16 dense issued") if f16x3 else
+                             "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         "roofline_resample": {"bound": "hbm", "kernel": "e2p_lds_kernel + p2e_kernel<float,8,false,true> at 18x256^2, B=%d" % B,
                               "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
                               "traffic": None,

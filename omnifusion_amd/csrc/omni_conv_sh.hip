@@ -56,19 +56,18 @@ __device__ __forceinline__ void dma16(rsrc_t rs, unsigned char* lds, int voff, i
 // s_waitcnt vmcnt(N) with a compile-time count (the LDS-DMA pieces still allowed in flight)
 template <int N> __device__ __forceinline__ void wait_vm()
 {
-    static_assert(N >= 0 && N <= 24, "vmcnt out of the range spelled out below");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else static_assert(N < 0, "add the literal for this count");
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+#define OMNI_VM(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory");
+    if constexpr (N < 0) {}
+    OMNI_VM(0) OMNI_VM(1) OMNI_VM(2) OMNI_VM(3) OMNI_VM(4) OMNI_VM(5) OMNI_VM(6) OMNI_VM(7)
+    OMNI_VM(8) OMNI_VM(9) OMNI_VM(10) OMNI_VM(11) OMNI_VM(12) OMNI_VM(13) OMNI_VM(14) OMNI_VM(15)
+    OMNI_VM(16) OMNI_VM(17) OMNI_VM(18) OMNI_VM(19) OMNI_VM(20) OMNI_VM(21) OMNI_VM(22) OMNI_VM(23)
+    OMNI_VM(24) OMNI_VM(25) OMNI_VM(26) OMNI_VM(27) OMNI_VM(28) OMNI_VM(29) OMNI_VM(30) OMNI_VM(31)
+    OMNI_VM(32) OMNI_VM(33) OMNI_VM(34) OMNI_VM(35) OMNI_VM(36) OMNI_VM(37) OMNI_VM(38) OMNI_VM(39)
+    OMNI_VM(40) OMNI_VM(41) OMNI_VM(42) OMNI_VM(43) OMNI_VM(44) OMNI_VM(45) OMNI_VM(46) OMNI_VM(47)
+    OMNI_VM(48) OMNI_VM(49) OMNI_VM(50) OMNI_VM(51) OMNI_VM(52) OMNI_VM(53) OMNI_VM(54) OMNI_VM(55)
+    OMNI_VM(56) OMNI_VM(57) OMNI_VM(58) OMNI_VM(59) OMNI_VM(60) OMNI_VM(61) OMNI_VM(62) OMNI_VM(63)
+#undef OMNI_VM
 }
 
 struct ShConvArgs {
@@ -84,6 +83,46 @@ struct ShConvArgs {
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
     int dbg;                                 // OMNI_CONV_DBG ablation bits (tuning only): 1 no MFMA, 2 no re-issue
 };
+
+// Fused epilogue of NT accumulator tiles of ONE pixel row r (D = W x pixels: a lane holds, per register quad q, the four
+// consecutive channels c0[j] + 8q + 4(lane>>5) .. +3 of its pixel).  Two phases: every bias / residual load is issued
+// before the first store, so the loads overlap instead of serialising load -> wait -> store once per quad.
+template <int NT>
+__device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r,
+                                             const int (&c0)[NT], int lane, bool dst_sh)
+{
+    f4v bq[NT * 4]; h4v rh[NT * 4], rl[NT * 4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0[j] + 8 * q + 4 * (lane >> 5);
+            bq[j * 4 + q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + c) : (f4v)(0.0f);
+            if (a.res) {
+                const unsigned char* rp = (const unsigned char*)a.res + sh_off(r * a.Cout + c);
+                rh[j * 4 + q] = *reinterpret_cast<const h4v*>(rp); rl[j * 4 + q] = *reinterpret_cast<const h4v*>(rp + 64);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0[j] + 8 * q + 4 * (lane >> 5);
+            f4v v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
+            v += bq[j * 4 + q];
+            if (a.res) v += sh_join4(rh[j * 4 + q], rl[j * 4 + q]);
+            if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            }
+            const size_t o = r * a.Cout + c;
+            if (dst_sh) act_store4<true>(a.dst, o, v);
+            else        act_store4<false>(a.dst, o, v);
+        }
+}
 
 template <int BM, int BN, int WM, int WN, int NST, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
@@ -240,37 +279,22 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
     for (int i = 0; i < TM; ++i) {
         const int r = row0 + wm * (BM / WM) + i * 32 + (lane & 31);
         if (r >= a.rows) continue;
+        if (a.splitk > 1) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = col0 + wn * (BN / WN) + j * 32 + 8 * q + 4 * (lane >> 5);
-                f4v v;
+                for (int q = 0; q < 4; ++q) {
+                    const int c = col0 + wn * (BN / WN) + j * 32 + 8 * q + 4 * (lane >> 5);
+                    f4v v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[i][j][4 * q + e], 4.8828125e-4f, acc[i][j][4 * q + e]);
-                const size_t o = (size_t)r * a.Cout + c;
-                if (a.splitk > 1) {
-                    *reinterpret_cast<f4v*>(a.ws + (size_t)blockIdx.y * a.rows * a.Cout + o) = v;
-                    continue;
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[i][j][4 * q + e], 4.8828125e-4f, acc[i][j][4 * q + e]);
+                    *reinterpret_cast<f4v*>(a.ws + ((size_t)blockIdx.y * a.rows + r) * a.Cout + c) = v;
                 }
-                if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + c);
-                if (a.res) {
-                    const unsigned char* rp = (const unsigned char*)a.res + sh_off(o);
-                    v += sh_join4(*reinterpret_cast<const h4v*>(rp), *reinterpret_cast<const h4v*>(rp + 64));
-                }
-                if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                else if (a.act == OMNI_ACT_GELU) {
+        } else {
+            int c0[TN];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-                }
-                if (a.dst_sh) {
-                    h4v hi, lo; sh_split4(v, hi, lo);
-                    unsigned char* dp = (unsigned char*)a.dst + sh_off(o);
-                    *reinterpret_cast<h4v*>(dp) = hi; *reinterpret_cast<h4v*>(dp + 64) = lo;
-                } else {
-                    *reinterpret_cast<f4v*>((float*)a.dst + o) = v;
-                }
-            }
+            for (int j = 0; j < TN; ++j) c0[j] = col0 + wn * (BN / WN) + j * 32;
+            epilogue_row<TN>(acc[i], acc1[i], a, (size_t)r, c0, lane, a.dst_sh != 0);
         }
     }
 }
@@ -407,26 +431,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
 
     // ---- epilogue (as conv_sh_kernel): column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
     const int r = (m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
+    int c0[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = col0 + j * 32 + 8 * q + 4 * (lane >> 5);
-            f4v v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
-            const size_t o = (size_t)r * a.Cout + c;
-            if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + c);
-            if (a.res) v += act_load4<true>(a.res, o);
-            if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            else if (a.act == OMNI_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-            }
-            if (a.dst_sh) act_store4<true>(a.dst, o, v);
-            else          act_store4<false>(a.dst, o, v);
-        }
-    }
+    for (int j = 0; j < TN; ++j) c0[j] = col0 + j * 32;
+    epilogue_row<TN>(acc, acc1, a, (size_t)r, c0, lane, a.dst_sh != 0);
 }
 
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
@@ -544,6 +552,8 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
             case 32: launch_sh<128, 128, 2, 2, 3, 16>(a, s); break;
             case 33: launch_sh<64, 64, 2, 2, 4, 16>(a, s); break;
             case 40: launch_sh<64, 64, 2, 2, 3>(a, s); break;
+            case 41: launch_sh<64, 64, 2, 2, 2, 16>(a, s); break;
+            case 42: launch_sh<64, 64, 2, 2, 2>(a, s); break;
             default: launch_sh<64, 64, 2, 2, 3, 16>(a, s); break;
         }
     }

@@ -27,6 +27,7 @@
 // CONSECUTIVE channels of ONE pixel per register quad: bias / residual / output move as 8-byte (SH) or 16-byte (fp32)
 // pieces instead of scalars.
 #include <stdlib.h>
+#include <type_traits>
 #include "omni_internal.h"
 #include "omni_sh.h"
 
@@ -81,7 +82,6 @@ struct ShConvArgs {
     int rows;                                // M*Ho*Wo
     int dst_sh;
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
-    int dbg;                                 // OMNI_CONV_DBG ablation bits (tuning only): 1 no MFMA, 2 no re-issue
 };
 
 // Fused epilogue of NT accumulator tiles of ONE pixel row r (D = W x pixels: a lane holds, per register quad q, the four
@@ -124,20 +124,22 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
         }
 }
 
-template <int BM, int BN, int WM, int WN, int NST, int DBG = 0>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
 {
+    constexpr int NST = 3;                                      // stages in flight (the step loop is unrolled by it)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
     constexpr int APASS = BM / 32, BPASS = BN / 32, LPS = APASS + BPASS;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: LDS-DMA bases stay in scalar registers
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = a.Cout / BN;
     const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x % ntn;
     const int row0 = tile_m * BM, col0 = tile_n * BN;
-    const int G1 = a.C1 >> 5, G = (a.C1 + a.C2) >> 5;
+    const int G1 = a.C1 >> 5, G2 = a.C2 >> 5, G = G1 + G2;
     const int ksteps = a.KH * a.KW * G;
 
     // ---- DMA geometry: instruction j of a tile covers LDS row pairs 4j .. 4j+3; wave w issues j = w, w+4, ...  Lane i
@@ -173,32 +175,47 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) wbase[i] = (col0 + rl + 32 * i) * ksteps * 128 + pc16;
 
-    int f_tap = 0, f_g = 0, f_ky = 0, f_kx = 0;                  // (tap, channel group) of the NEXT stage to issue
-    auto seek = [&](int ks) { f_tap = ks / G; f_g = ks - f_tap * G; f_ky = f_tap / a.KW; f_kx = f_tap - f_ky * a.KW; };
-    auto issue = [&](int ks, int slot) {
-        const bool first = f_g < G1;
-        const int cs4 = (first ? a.C1 : a.C2) * 4;               // pixel pitch in bytes of the source in use
-        const int soff = (f_ky * a.W + f_kx) * cs4 + (first ? f_g : f_g - G1) * 128 + pc16;
-        unsigned char* sb = lds + slot * STAGE + wave * 1024;
-        // (the range check of a raw buffer access sees the VGPR offset only and the origin of a padded window may lie
-        //  before the tensor: the tap term is folded into the VGPR offset)
-        if (first) {
+    // ---- issue side.  The K order is (tap, source, 32-channel group); everything that depends on the lane is recomputed
+    // only when (tap, source) changes — voff[i] = byte offset of this lane's piece for group 0, or out of range for a tap
+    // outside the image — so that a K-step costs one scalar offset and LPS DMA instructions, nothing per lane.  (The matrix
+    // pipe retires one MFMA per 32 cycles per SIMD, in which a SIMD has 8 issue slots: a loop with ~20 scalar/vector
+    // instructions per MFMA, as the first version of this kernel had, is issue-bound at ~30 % of the MFMA rate.)
+    int f_tap = 0, f_src = 0, f_gl = 0, f_ky = 0, f_kx = 0, f_gn = G1;
+    int voff[APASS];
+    auto refresh = [&]() {
+        const int cs4 = (f_src ? a.C2 : a.C1) * 4;
+        const int toff = (f_ky * a.W + f_kx) * cs4 + pc16;
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) {
-                const int off = ((vmask[i] >> f_tap) & 1u) ? pix[i] * cs4 + soff : (int)0x80000000;
-                dma16(rs1, sb + i * 4096, off, 0);
-            }
+        for (int i = 0; i < APASS; ++i)
+            // (the range check of a raw buffer access sees the VGPR offset only and the origin of a padded window may lie
+            //  before the tensor: the tap term is folded into the VGPR offset)
+            voff[i] = ((vmask[i] >> f_tap) & 1u) ? pix[i] * cs4 + toff : (int)0x80000000;
+    };
+    auto seek = [&](int ks) {
+        f_tap = ks / G; const int g = ks - f_tap * G;
+        f_src = g >= G1; f_gl = f_src ? g - G1 : g; f_gn = f_src ? G2 : G1;
+        f_ky = f_tap / a.KW; f_kx = f_tap - f_ky * a.KW;
+        refresh();
+    };
+    auto issue = [&](int ks, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        unsigned char* sb = lds + SLOT * STAGE + wave * 1024;
+        const int so = f_gl * 128;
+        if (f_src) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) dma16(rs2, sb + i * 4096, voff[i], so);
         } else {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) {
-                const int off = ((vmask[i] >> f_tap) & 1u) ? pix[i] * cs4 + soff : (int)0x80000000;
-                dma16(rs2, sb + i * 4096, off, 0);
-            }
+            for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * 4096, voff[i], so);
         }
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-            dma16(rsw, sb + A_BYTES + i * 4096, wbase[i], ks * 128);
-        if (++f_g == G) { f_g = 0; ++f_tap; if (++f_kx == a.KW) { f_kx = 0; ++f_ky; } }
+        for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * 4096, wbase[i], ks * 128);
+        if (++f_gl == f_gn) {
+            f_gl = 0;
+            if (f_src == 0 && G2 > 0) { f_src = 1; f_gn = G2; }
+            else { f_src = 0; f_gn = G1; ++f_tap; if (++f_kx == a.KW) { f_kx = 0; ++f_ky; } }
+            refresh();
+        }
     };
 
     f16v acc[TM][TN], acc1[TM][TN];                              // acc = hi.hi, acc1 = hi.lo + lo.hi (scaled by 2^11)
@@ -207,12 +224,17 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
 #pragma unroll
         for (int j = 0; j < TN; ++j) { acc[i][j] = (f16v)(0.0f); acc1[i][j] = (f16v)(0.0f); }
 
-    // fragment offsets: row lane&31 of a 32-row tile, piece p = 2k + (lane>>5): k = 0,1 hi of the two 16-wide k chunks, 2,3 lo
-    int fo[4];
+    // fragment offsets: row lane&31 of a 32-row tile, piece p = 2k + (lane>>5): k = 0,1 hi of the two 16-wide k chunks, 2,3 lo;
+    // the wave's tile origin is folded in, the stage offset is an immediate of the unrolled step
+    int foa[4], fob[4];
     {
         const int r = lane & 31, v = r >> 1, h = lane >> 5;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+        for (int k = 0; k < 4; ++k) {
+            const int f = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+            foa[k] = f + wm * (BM / WM) * 128;
+            fob[k] = f + A_BYTES + wn * (BN / WN) * 128;
+        }
     }
 
     int ks_begin = 0, ks_end = ksteps;
@@ -220,60 +242,57 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
         const int per = (ksteps + a.splitk - 1) / a.splitk;
         ks_begin = blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
     }
-    if (DBG & 8) ks_end = ks_begin;
     seek(ks_begin);
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (ks_begin + s < ks_end) issue(ks_begin + s, s);
-    int slot = 0, islot = NST - 1;
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
-        else                       wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
+    if (ks_begin < ks_end) issue(ks_begin, std::integral_constant<int, 0>());
+    if (ks_begin + 1 < ks_end) issue(ks_begin + 1, std::integral_constant<int, 1>());
+
+    auto step = [&](int ks, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (ks + 1 < ks_end) wait_vm<LPS>();                     // my pieces of stage ks have landed (those of ks+1 may fly)
+        else                 wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                            // ... everybody's have; everybody is done reading stage ks-1
         asm volatile("" ::: "memory");
-        const bool more = ks + NST - 1 < ks_end && !(DBG & 2);
-        if (!(DBG & 16) && more) issue(ks + NST - 1, islot);
-        const unsigned char* sA = lds + slot * STAGE + wm * (BM / WM) * 128;
-        const unsigned char* sB = lds + slot * STAGE + A_BYTES + wn * (BN / WN) * 128;
-        if (DBG & 1) {
-            if ((DBG & 16) && more) issue(ks + NST - 1, islot);
-        } else {
-            h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        const unsigned char* sl = lds + SLOT * STAGE;
+        h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
+        for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[kc][i] = *reinterpret_cast<const h8v*>(sA + i * 4096 + fo[kc]);
-                    al[kc][i] = *reinterpret_cast<const h8v*>(sA + i * 4096 + fo[2 + kc]);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[kc][j] = *reinterpret_cast<const h8v*>(sB + j * 4096 + fo[kc]);
-                    bl[kc][j] = *reinterpret_cast<const h8v*>(sB + j * 4096 + fo[2 + kc]);
-                }
+            for (int i = 0; i < TM; ++i) {
+                ah[kc][i] = *reinterpret_cast<const h8v*>(sl + i * 4096 + foa[kc]);
+                al[kc][i] = *reinterpret_cast<const h8v*>(sl + i * 4096 + foa[2 + kc]);
             }
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                if (DBG & 16) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
-                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);
-                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);
-                    }
-                if ((DBG & 16) && kc == 0) {          // the next stage's DMA is issued under the first half's matrix work
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) issue(ks + NST - 1, islot);
-                }
+            for (int j = 0; j < TN; ++j) {
+                bh[kc][j] = *reinterpret_cast<const h8v*>(sl + j * 4096 + fob[kc]);
+                bl[kc][j] = *reinterpret_cast<const h8v*>(sl + j * 4096 + fob[2 + kc]);
             }
         }
-        if (++islot == NST) islot = 0;
-        if (++slot == NST) slot = 0;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);
+                }
+            if (kc == 0) {                                       // the stage after next, issued under the first half's matrix work
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < ks_end) issue(ks + 2, std::integral_constant<int, (SLOT + 2) % NST>());
+            }
+        }
+    };
+    int ks = ks_begin;
+    for (; ks + 2 < ks_end; ks += 3) {                           // (no early exits inside: they would park the accumulators in VGPRs)
+        step(ks, std::integral_constant<int, 0>());
+        step(ks + 1, std::integral_constant<int, 1>());
+        step(ks + 2, std::integral_constant<int, 2>());
     }
+    if (ks < ks_end) step(ks, std::integral_constant<int, 0>());
+    if (ks + 1 < ks_end) step(ks + 1, std::integral_constant<int, 1>());
 
-    if (DBG & 4) return;
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -483,11 +502,11 @@ __global__ __launch_bounds__(256) void sh_to_f32_kernel(const void* __restrict__
     *reinterpret_cast<f4v*>(dst + i * 4) = sh_join4(*reinterpret_cast<const h4v*>(sp), *reinterpret_cast<const h4v*>(sp + 64));
 }
 
-template <int BM, int BN, int WM, int WN, int NST, int DBG = 0>
+template <int BM, int BN, int WM, int WN>
 void launch_sh(const ShConvArgs& a, hipStream_t s)
 {
     const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, DBG>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
 }
 }  // namespace
 
@@ -521,7 +540,6 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
     a.splitk = S > 1 ? S : 1; a.ws = ws;
-    { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
     hipStream_t s = (hipStream_t)stream;
     if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % HT_H == 0 && !getenv("OMNI_CONV_NOHALO")) {
         const int grid = M * (H / HT_H) * (W / HT_W);
@@ -533,30 +551,10 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     // tile: results do not depend on it (every output element is the same k-ordered chain), so it is a pure tuning choice
     int tile = 0;                                                  // 0: 64x64, 1: 128x64, 2: 128x128
     { const char* e = getenv("OMNI_CONV_SH_TILE"); if (e) tile = atoi(e); }
-    if (Cout % 64 != 0) {
-        if (tile == 1) launch_sh<256, 32, 4, 1, 3>(a, s);
-        else           launch_sh<128, 32, 4, 1, 4>(a, s);
-    } else {
-        if (tile == 2 && Cout % 128 != 0) tile = 1;
-        switch (tile) {
-            case 2: launch_sh<128, 128, 2, 2, 3>(a, s); break;
-            case 1: launch_sh<128, 64, 2, 2, 3>(a, s); break;
-            case 3: launch_sh<64, 64, 2, 2, 4>(a, s); break;
-            case 11: launch_sh<64, 64, 2, 2, 3, 1>(a, s); break;
-            case 12: launch_sh<64, 64, 2, 2, 3, 2>(a, s); break;
-            case 13: launch_sh<64, 64, 2, 2, 3, 3>(a, s); break;
-            case 17: launch_sh<64, 64, 2, 2, 3, 7>(a, s); break;
-            case 21: launch_sh<64, 64, 2, 2, 3, 11>(a, s); break;
-            case 25: launch_sh<64, 64, 2, 2, 3, 15>(a, s); break;
-            case 31: launch_sh<128, 64, 2, 2, 3, 16>(a, s); break;
-            case 32: launch_sh<128, 128, 2, 2, 3, 16>(a, s); break;
-            case 33: launch_sh<64, 64, 2, 2, 4, 16>(a, s); break;
-            case 40: launch_sh<64, 64, 2, 2, 3>(a, s); break;
-            case 41: launch_sh<64, 64, 2, 2, 2, 16>(a, s); break;
-            case 42: launch_sh<64, 64, 2, 2, 2>(a, s); break;
-            default: launch_sh<64, 64, 2, 2, 3, 16>(a, s); break;
-        }
-    }
+    if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s);
+    else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s);
+    else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
+    else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
     if (a.splitk > 1) {
         const size_t n4 = (size_t)rows * Cout / 4;

@@ -145,10 +145,11 @@ int omni_conv2d_nhwc_f16x3_ws(const float* src1, const float* src2, const void* 
                               omni_stream_t stream);
 /* The same operator with SPLIT-HALF ("SH") activations: per pixel and per group of 32 channels a tensor stores 32 hi
  * halfs then 32 lo halfs (x = hi + lo*2^-11; 128 bytes per group = the footprint of 32 floats).  The producer splits
- * once, consumers stream tiles straight into LDS by LDS-DMA.  src1, src2 and res are SH tensors; dst is SH when
- * dst_sh != 0, else fp32 NHWC; wt16 as above.  omni_sh_from_f32 / omni_sh_to_f32 convert n elements (n % 32 == 0). */
+ * once, consumers stream tiles straight into LDS by LDS-DMA.  src1 and src2 are SH tensors; fmt bit 0: dst is SH
+ * (else fp32 NHWC), fmt bit 1: res is fp32 NHWC (else SH); wt16 as above.  omni_sh_from_f32 / omni_sh_to_f32 convert
+ * n elements (n % 32 == 0). */
 int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
-                            const void* res, void* dst, int dst_sh, int M, int H, int W, int C1, int C2, int Cout,
+                            const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                             int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                             omni_stream_t stream);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
@@ -171,6 +172,10 @@ int omni_maxpool3x3s2_sh(const void* src, void* dst, int M, int H, int W, int C,
 int omni_upsample_bilinear_sh(const void* src, void* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream);
 int omni_add_hw_sh(void* x, const float* y, int M, int HW, int C, omni_stream_t stream);
 int omni_add_period_sh(void* x, const float* y, size_t total, size_t period, omni_stream_t stream);
+/* nn.LayerNorm(512) with an SH result, and the attention core on a fused q|k|v projection [B*N, 1536] (q at column 0,
+ * k at 512, v at 1024; heads of 128) with an SH result: the f16x3 GEMMs of the transformer consume them directly. */
+int omni_layernorm512_sh(const float* x, const float* g, const float* b, void* y, int rows, float eps, omni_stream_t stream);
+int omni_attention_qkv_sh(const float* qkv, void* out, int B, int N, omni_stream_t stream);
 /* tokens: reshape(bs,-1,N).transpose(1,2) of the `down` output + pos_emb, model/spherical_model.py:264,181 */
 int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream);
 /* nn.LayerNorm(512), model/blocks.py:74,81 (eps 1e-5) and model/spherical_model.py:173 (eps 1e-6) */

@@ -81,6 +81,7 @@ struct ShConvArgs {
     int KH, KW, stride, pad, act;
     int rows;                                // M*Ho*Wo
     int dst_sh;
+    int res_f32;                             // residual is plain fp32 NHWC instead of SH
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
 };
 
@@ -91,14 +92,15 @@ template <int NT>
 __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r,
                                              const int (&c0)[NT], int lane, bool dst_sh)
 {
-    f4v bq[NT * 4]; h4v rh[NT * 4], rl[NT * 4];
+    f4v bq[NT * 4], rf[NT * 4]; h4v rh[NT * 4], rl[NT * 4];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = c0[j] + 8 * q + 4 * (lane >> 5);
             bq[j * 4 + q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + c) : (f4v)(0.0f);
-            if (a.res) {
+            if (a.res && a.res_f32) rf[j * 4 + q] = *reinterpret_cast<const f4v*>((const float*)a.res + r * a.Cout + c);
+            else if (a.res) {
                 const unsigned char* rp = (const unsigned char*)a.res + sh_off(r * a.Cout + c);
                 rh[j * 4 + q] = *reinterpret_cast<const h4v*>(rp); rl[j * 4 + q] = *reinterpret_cast<const h4v*>(rp + 64);
             }
@@ -112,7 +114,8 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
             v += bq[j * 4 + q];
-            if (a.res) v += sh_join4(rh[j * 4 + q], rl[j * 4 + q]);
+            if (a.res && a.res_f32) v += rf[j * 4 + q];
+            else if (a.res) v += sh_join4(rh[j * 4 + q], rl[j * 4 + q]);
             if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (a.act == OMNI_ACT_GELU) {
 #pragma unroll
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
 __global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                const void* __restrict__ res, void* __restrict__ dst,
-                                                               size_t n4, int Cout, int splitk, size_t slab, int act, int dst_sh)
+                                                               size_t n4, int Cout, int splitk, size_t slab, int act, int dst_sh, int res_f32)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
@@ -467,7 +470,8 @@ __global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __re
     f4v v = *reinterpret_cast<const f4v*>(ws + o);
     for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f4v*>(ws + (size_t)s * slab + o);
     if (bias) v += *reinterpret_cast<const f4v*>(bias + (o % Cout));
-    if (res) {
+    if (res && res_f32) v += *reinterpret_cast<const f4v*>((const float*)res + o);
+    else if (res) {
         const unsigned char* rp = (const unsigned char*)res + sh_off(o);
         v += sh_join4(*reinterpret_cast<const h4v*>(rp), *reinterpret_cast<const h4v*>(rp + 64));
     }
@@ -511,20 +515,22 @@ void launch_sh(const ShConvArgs& a, hipStream_t s)
 }  // namespace
 
 // out[M,Ho,Wo,Cout] = act(conv(src1 ++ src2, wt16) + bias + res) with SH activations (see the file header).
-// src1/src2/res: SH tensors; dst: SH when dst_sh != 0, else fp32 NHWC; wt16 as for omni_conv2d_nhwc_f16x3_ws.
+// src1/src2: SH tensors; fmt bit 0: dst is SH (else fp32 NHWC); fmt bit 1: res is fp32 NHWC (else SH); wt16 as for
+// omni_conv2d_nhwc_f16x3_ws.  A plain GEMM is the case H = W = KH = KW = 1 (rows = M).
 // Requirements: C1, C2, Cout multiples of 32, kernels up to 3x3.  split-K as in omni_conv2d_nhwc_f32_ws.
 extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
-                                       const void* res, void* dst, int dst_sh, int M, int H, int W, int C1, int C2, int Cout,
+                                       const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                        int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                                        omni_stream_t stream)
 {
+    const int dst_sh = fmt & 1;
     if (!src1 || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: null pointer");
     if (C1 <= 0 || C1 % 32 || C2 < 0 || C2 % 32 || Cout <= 0 || Cout % 32 || (C2 > 0 && !src2))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: channels must be multiples of 32");
     if (M <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || KH > 3 || KW > 3 || stride <= 0 || pad < 0)
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: bad shape (kernels up to 3x3)");
     ShConvArgs a;
-    a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh;
+    a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh; a.res_f32 = (fmt >> 1) & 1;
     a.M = M; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
@@ -559,7 +565,7 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     if (a.splitk > 1) {
         const size_t n4 = (size_t)rows * Cout / 4;
         hipLaunchKernelGGL(sh_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, bias, res, dst,
-                           n4, Cout, a.splitk, (size_t)rows * Cout, act, dst_sh);
+                           n4, Cout, a.splitk, (size_t)rows * Cout, act, a.dst_sh, a.res_f32);
         OMNI_HIP(hipGetLastError());
     }
     return OMNI_OK;

@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256) void token_pack_kernel(const float* __restrict
 }
 
 // one wave per row of 512
+template <bool SH>
 __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                           const float* __restrict__ b, float* __restrict__ y, int rows, float eps)
+                                                           const float* __restrict__ b, void* __restrict__ y, int rows, float eps)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -189,14 +190,16 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
     const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + eps);
     const f4v g0 = *reinterpret_cast<const f4v*>(g + lane * 4), g1 = *reinterpret_cast<const f4v*>(g + 256 + lane * 4);
     const f4v b0 = *reinterpret_cast<const f4v*>(b + lane * 4), b1 = *reinterpret_cast<const f4v*>(b + 256 + lane * 4);
-    float* o = y + (size_t)row * 512;
-    *reinterpret_cast<f4v*>(o + lane * 4) = v0 * rstd * g0 + b0;
-    *reinterpret_cast<f4v*>(o + 256 + lane * 4) = v1 * rstd * g1 + b1;
+    const size_t o = (size_t)row * 512;
+    act_store4<SH>(y, o + lane * 4, v0 * rstd * g0 + b0);
+    act_store4<SH>(y, o + 256 + lane * 4, v1 * rstd * g1 + b1);
 }
 
 // attention core: block = (batch item, head); N <= 64 tokens, head dim 128.
+// q rows have pitch qs floats, k|v rows pitch kvs (k at column 0, v at column vo); SH: the result is a split-half tensor
+template <bool SH>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                        float* __restrict__ out, int N, float scale)
+                                                        void* __restrict__ out, int N, float scale, int qs, int kvs, int vo)
 {
     __shared__ float ks[64][129];
     __shared__ float vs[64][128];
@@ -205,12 +208,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     for (int i = t; i < N * 128; i += 256) {
         const int j = i >> 7, d = i & 127;
-        const float* row = kv + (size_t)(b * N + j) * 1024 + h * 128 + d;
-        ks[j][d] = row[0]; vs[j][d] = row[512];
+        const float* row = kv + (size_t)(b * N + j) * kvs + h * 128 + d;
+        ks[j][d] = row[0]; vs[j][d] = row[vo];
     }
     __syncthreads();
     for (int i = wave; i < N; i += 4) {
-        const float* qi = q + (size_t)(b * N + i) * 512 + h * 128;
+        const float* qi = q + (size_t)(b * N + i) * qs + h * 128;
         float s = -INFINITY;
         if (lane < N) {
             float acc = 0.0f;
@@ -228,8 +231,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         __builtin_amdgcn_wave_barrier();
         float o0 = 0.0f, o1 = 0.0f;
         for (int j = 0; j < N; ++j) { const float pj = ps[wave][j]; o0 = fmaf(pj, vs[j][lane], o0); o1 = fmaf(pj, vs[j][lane + 64], o1); }
-        float* oi = out + (size_t)(b * N + i) * 512 + h * 128;
-        oi[lane] = o0; oi[lane + 64] = o1;
+        if (SH) {                                                 // channel c of a row: group c>>5, hi half at 2*(c&31), lo 64 bytes on
+            unsigned char* orow = (unsigned char*)out + (size_t)(b * N + i) * 2048 + h * 512;
+            const float ov[2] = {o0, o1};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = lane + 64 * u;
+                const float x = ov[u];
+                const _Float16 hi = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+                _Float16* gp = reinterpret_cast<_Float16*>(orow + (c >> 5) * 128) + (c & 31);
+                gp[0] = hi; gp[32] = (_Float16)((x - (float)hi) * 2048.0f);
+            }
+        } else {
+            float* oi = (float*)out + (size_t)(b * N + i) * 512 + h * 128;
+            oi[lane] = o0; oi[lane + 64] = o1;
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -380,6 +396,17 @@ int omni_add_period_sh(void* x, const float* y, size_t total, size_t period, omn
     hipLaunchKernelGGL(add_period_sh_kernel, dim3(nblk(total / 4)), dim3(256), 0, S_, x, y, total / 4, period);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
+int omni_layernorm512_sh(const float* x, const float* g, const float* b, void* y, int rows, float eps, omni_stream_t stream)
+{
+    hipLaunchKernelGGL(layernorm512_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, S_, x, g, b, y, rows, eps);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
+int omni_attention_qkv_sh(const float* qkv, void* out, int B, int N, omni_stream_t stream)
+{
+    if (N > 64) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_attention: at most 64 tokens");
+    hipLaunchKernelGGL(attention_kernel<true>, dim3(B * 4), dim3(256), 0, S_, qkv, qkv + 512, out, N, 0.08838834764831845f, 1536, 1536, 512);
+    OMNI_HIP(hipGetLastError()); return OMNI_OK;
+}
 int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream)
 {
     hipLaunchKernelGGL(token_pack_kernel, dim3(nblk((size_t)M * HW * C)), dim3(256), 0, S_, d, pos, tok, M, N, HW, C);
@@ -387,13 +414,13 @@ int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int
 }
 int omni_layernorm512_f32(const float* x, const float* g, const float* b, float* y, int rows, float eps, omni_stream_t stream)
 {
-    hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, S_, x, g, b, y, rows, eps);
+    hipLaunchKernelGGL(layernorm512_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, S_, x, g, b, (void*)y, rows, eps);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_attention_f32(const float* q, const float* kv, float* out, int B, int N, omni_stream_t stream)
 {
     if (N > 64) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_attention: at most 64 tokens");
-    hipLaunchKernelGGL(attention_kernel, dim3(B * 4), dim3(256), 0, S_, q, kv, out, N, 0.08838834764831845f /* 128^-1/2 */);
+    hipLaunchKernelGGL(attention_kernel<false>, dim3(B * 4), dim3(256), 0, S_, q, kv, (void*)out, N, 0.08838834764831845f /* 128^-1/2 */, 512, 1024, 512);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_heads_f32(const float* x, const float* w, float bias_pred, float bias_weight, float* out_a, float* out_c,

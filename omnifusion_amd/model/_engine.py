@@ -106,6 +106,11 @@ class Engine:
             for k in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.q.weight", "attn.kv.weight",
                       "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"):
                 W[f"t{i}.{k}"] = f(sd[f"{p}.{k}"])
+        for i in range(6):                                                       # f16x3 operands of the transformer GEMMs
+            t = f"t{i}."
+            W[t + "attn.qkv.w16"] = split_weights_f16x3(torch.cat([W[t + "attn.q.weight"], W[t + "attn.kv.weight"]], 0).cpu()).to(dev)
+            for k in ("attn.proj", "mlp.fc1", "mlp.fc2"):
+                W[t + k + ".w16"] = split_weights_f16x3(W[t + k + ".weight"].cpu()).to(dev)
         W["enc_norm.w"] = f(sd["transformer.encoder_norm.weight"]); W["enc_norm.b"] = f(sd["transformer.encoder_norm.bias"])
         hw = torch.stack([sd["pred.weight"][0, :, :, :, 0], sd["weight_pred.weight"][0, :, :, :, 0]])    # [2,32,3,3]
         W["heads.w"] = f(hw.permute(0, 2, 3, 1).reshape(2, 9, 32))
@@ -184,6 +189,22 @@ class Engine:
         _lib.check(rc, "gemm " + wkey)
         return out
 
+    def _gemm_sh(self, x, w16key, bkey, rows, K, Nout, act=ACT_NONE, res=None, out_sh=False):
+        """f16x3 GEMM on an SH activation matrix x [rows, K]; res (fp32) and bias optional; result fp32 or SH"""
+        lib = _lib.load()
+        out = torch.empty((rows, Nout), dtype=torch.float32, device=x.device)
+        S, ws, nb = (1, None, 0) if K <= 512 else self._splitk(rows, Nout, K // 32, x.device)
+        rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), None, _p(self.w[w16key]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
+                                         (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws),
+                                         ctypes.c_size_t(nb), self._s)
+        _lib.check(rc, "gemm " + w16key)
+        return out
+
+    def _ln_sh(self, x, wk, bk, rows, eps):
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().omni_layernorm512_sh(_p(x), _p(self.w[wk]), _p(self.w[bk]), _p(y), rows, ctypes.c_float(eps), self._s), "layernorm")
+        return y
+
     def _ln(self, x, wk, bk, rows, eps):
         y = torch.empty_like(x)
         _lib.check(_lib.load().omni_layernorm512_f32(_p(x), _p(self.w[wk]), _p(self.w[bk]), _p(y), rows, ctypes.c_float(eps), self._s), "layernorm")
@@ -241,6 +262,16 @@ class Engine:
         _lib.check(lib.omni_token_pack_f32(_p(d), _p(self.w["pos"]), _p(tok), M, N, P32 * P32, 32, self._s), "token_pack")
         for i in range(6):
             t = f"t{i}."
+            if sh:                                                   # LN / attention emit SH, the GEMMs run f16x3 from it
+                y = self._ln_sh(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)
+                qkv = self._gemm_sh(y, t + "attn.qkv.w16", None, M, 512, 1536)
+                att = new(M, 512)
+                _lib.check(lib.omni_attention_qkv_sh(_p(qkv), _p(att), bs, N, self._s), "attention")
+                tok = self._gemm_sh(att, t + "attn.proj.w16", t + "attn.proj.bias", M, 512, 512, res=tok)
+                y = self._ln_sh(tok, t + "norm2.weight", t + "norm2.bias", M, 1e-5)
+                h = self._gemm_sh(y, t + "mlp.fc1.w16", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU, out_sh=True)
+                tok = self._gemm_sh(h, t + "mlp.fc2.w16", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
+                continue
             y = self._ln(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)
             q = self._gemm(y, t + "attn.q.weight", None, M, 512, 512)
             kv = self._gemm(y, t + "attn.kv.weight", None, M, 512, 1024)

@@ -12,9 +12,11 @@ CFGS = [("layer1", 32, 32, 64, 0, 64, 3, 1, 1, True), ("layer2_0a", 32, 32, 64, 
         ("layer2", 16, 16, 128, 0, 128, 3, 1, 1, True), ("layer3_0a", 16, 16, 128, 0, 256, 3, 2, 1, False),
         ("layer3", 8, 8, 256, 0, 256, 3, 1, 1, True), ("layer4_0a", 8, 8, 256, 0, 512, 3, 2, 1, False),
         ("layer4", 4, 4, 512, 0, 512, 3, 1, 1, True),
-        ("de0_0", 8, 8, 512, 256, 256, 3, 1, 1, False), ("de1_0", 16, 16, 256, 128, 128, 3, 1, 1, False),
-        ("de2_0", 32, 32, 128, 64, 64, 3, 1, 1, False), ("de3_0", 64, 64, 64, 64, 64, 3, 1, 1, False),
-        ("de3_1", 64, 64, 64, 0, 32, 3, 1, 1, False), ("de4_0", 128, 128, 32, 0, 32, 3, 1, 1, False)]
+        ("de0_0", 8, 8, 512, 0, 256, 3, 1, 1, False), ("de0_1", 8, 8, 256, 256, 128, 3, 1, 1, False),
+        ("de1_0", 16, 16, 128, 0, 128, 3, 1, 1, False), ("de1_1", 16, 16, 128, 128, 64, 3, 1, 1, False),
+        ("de2_0", 32, 32, 64, 0, 64, 3, 1, 1, False), ("de2_1", 32, 32, 64, 64, 64, 3, 1, 1, False),
+        ("de3_0", 64, 64, 64, 0, 64, 3, 1, 1, False), ("de3_1", 64, 64, 64, 64, 32, 3, 1, 1, False),
+        ("de4_0", 128, 128, 32, 0, 32, 3, 1, 1, False)]
 if os.environ.get("ONLY"):
     CFGS = [CFGS[int(i)] for i in os.environ["ONLY"].split(",")]
 ws = torch.empty(64 << 20, device="cuda")

@@ -168,6 +168,9 @@ int omni_add_period_f32(float* x, const float* y, size_t total, size_t period, o
 /* The element-wise operators above on split-half (SH) activations (see omni_conv2d_sh_f16x3_ws): same arguments,
  * activation tensors in the SH layout (C % 32 == 0); the broadcast operand y and the stem's planar input stay fp32. */
 int omni_stem_sh(const float* src, const float* wt, const float* bias, void* dst, int M, int P, omni_stream_t stream);
+/* the stem as an implicit GEMM on the fp16 matrix cores (f16x3): wt16 = the folded filter bank [64][192], k = (c*7+ky)*8+kx
+ * (kx = 7 and k >= 168 zero), split into [64][6][hi32|lo32]; P % 32 == 0 */
+int omni_stem_sh_f16x3(const float* src, const void* wt16, const float* bias, void* dst, int M, int P, omni_stream_t stream);
 int omni_maxpool3x3s2_sh(const void* src, void* dst, int M, int H, int W, int C, omni_stream_t stream);
 int omni_upsample_bilinear_sh(const void* src, void* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream);
 int omni_add_hw_sh(void* x, const float* y, int M, int HW, int C, omni_stream_t stream);

@@ -459,6 +459,102 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
     epilogue_row<TN>(acc, acc1, a, (size_t)r, c0, lane, a.dst_sh != 0);
 }
 
+// ------------------------------------------------------------------ stem: conv 7x7 s2 p3, 3 -> 64, + folded BN + ReLU (f16x3)
+// model/spherical_model.py:254 (conv1, bn1, relu) as an implicit GEMM on the fp16 matrix cores.  K is laid out as
+// (c, ky, kx padded 7 -> 8): one 8-wide MFMA fragment is then 8 CONSECUTIVE input pixels of one (channel, kernel row) — four
+// ds_read_b64 from the fp32 input patch parked in LDS, split into hi/lo on the fly; K = 3*7*8 = 168, padded to 192 = 6
+// groups of 32 with zero weights.  A block owns an 8-row strip of one patch's output (Po columns in tiles of 16): the 64 x 192
+// pre-split filter bank (48 KiB) is DMA'd into LDS once per block, wave w owns output rows 2w, 2w+1 of the strip.
+// Output: SH [M, Po, Po, 64].
+constexpr int SM_TH = 8, SM_TW = 16, SM_IH = 2 * SM_TH + 5, SM_IW = 2 * SM_TW + 5, SM_IP = 40, SM_G = 6;
+
+__global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
+                                                         const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char wl[64 * SM_G * 128];
+    __shared__ __attribute__((aligned(16))) float img[3 * SM_IH * SM_IP];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int strips = Po / SM_TH;
+    const int m = blockIdx.x / strips, oy0 = (blockIdx.x % strips) * SM_TH;
+
+    // filter bank -> LDS: SM_G regions of 64 rows x 128 B, same pair swizzle as the convolution tiles
+    {
+        const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+        const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+        const rsrc_t rsw = make_rsrc(wt16, (size_t)64 * SM_G * 128);
+#pragma unroll
+        for (int g = 0; g < SM_G; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                dma16(rsw, wl + g * 8192 + wave * 1024 + i * 4096, ((rl + 32 * i) * SM_G + g) * 128 + pc16, 0);
+    }
+    int fo[4];
+    {
+        const int r = lane & 31, v = r >> 1, h = lane >> 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+    }
+    // this lane's output pixel inside a tile and its 12 fragment rows: fragment (g, kc) is input row (c, ky) = divmod(4g+2kc+h, 7)
+    const int py = 2 * wave + ((lane & 31) >> 4), px = lane & 15;
+    int rowoff[2 * SM_G];
+#pragma unroll
+    for (int f = 0; f < 2 * SM_G; ++f) {
+        int rr = 2 * f + (lane >> 5);
+        rr = rr < 21 ? rr : 20;                                   // rows 21..23 carry zero weights: any finite data will do
+        rowoff[f] = ((rr / 7) * SM_IH + rr % 7 + 2 * py) * SM_IP + 2 * px;
+    }
+    ShConvArgs e;
+    e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst;
+
+    for (int ox0 = 0; ox0 < Po; ox0 += SM_TW) {
+        const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+        __syncthreads();                                          // the previous tile's fragment reads are done
+        for (int i = t; i < 3 * SM_IH * SM_IP; i += 256) {        // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
+            const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
+            const int iy = iy0 + r, ix = ix0 + q;
+            float v = 0.0f;
+            if (q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) v = src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix];
+            img[i] = v;
+        }
+        if (ox0 == 0) wait_vm<0>();                               // the filter bank has landed
+        __syncthreads();
+        f16v acc[2], acc1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
+#pragma unroll
+        for (int g = 0; g < SM_G; ++g)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const float* ip = img + rowoff[2 * g + kc];
+                h8v ah, al;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 xv = *reinterpret_cast<const float2*>(ip + 2 * u);
+                    const float xs[2] = {xv.x, xv.y};
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const float x = xs[w];
+                        const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+                        ah[2 * u + w] = hh; al[2 * u + w] = (_Float16)((x - (float)hh) * 2048.0f);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char* bp = wl + g * 8192 + j * 4096;
+                    const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
+                    const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
+                }
+            }
+        const size_t r = ((size_t)m * Po + oy0 + py) * Po + ox0 + px;
+        const int c0[2] = {0, 32};
+        epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
+    }
+}
+
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
 __global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                const void* __restrict__ res, void* __restrict__ dst,
@@ -568,6 +664,19 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
                            n4, Cout, a.splitk, (size_t)rows * Cout, act, a.dst_sh, a.res_f32);
         OMNI_HIP(hipGetLastError());
     }
+    return OMNI_OK;
+}
+
+// conv1 7x7 s2 p3 (3 -> 64) + bn1 + ReLU on the fp16 matrix cores.  src planar [M,3,P,P]; wt16: the folded filter bank as
+// [64][192] with k = (c*7 + ky)*8 + kx (kx = 7 and k >= 168: zeros), split like every other f16x3 weight matrix
+// ([64][6][hi32|lo32]); dst SH [M,P/2,P/2,64].
+extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const float* bias, void* dst, int M, int P, omni_stream_t stream)
+{
+    if (!src || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_stem: null pointer");
+    if (P % 32 || M <= 0) OMNI_FAIL(OMNI_ERR_INVALID, "omni_stem_sh_f16x3: patch size must be a multiple of 32");
+    const int Po = P / 2;
+    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(M * (Po / SM_TH)), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po);
+    OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
 

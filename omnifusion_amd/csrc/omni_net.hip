@@ -125,6 +125,45 @@ __global__ __launch_bounds__(256) void upsample_kernel(const void* __restrict__ 
     act_store4<SH>(dst, (((size_t)m * Ho + oy) * Wo + ox) * C + c, o);
 }
 
+// SH -> SH, eight channels per thread (16-byte hi and lo pieces): half the instructions per byte of the generic form
+typedef _Float16 omni_h8v __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void upsample_sh8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                           int M, int H, int W, int C, int Ho, int Wo, float sy, float sx)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = C / 8;
+    const size_t total = (size_t)M * Ho * Wo * c8;
+    if (i >= total) return;
+    const int c = (int)(i % c8) * 8;
+    size_t r = i / c8;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); const int m = (int)(r / Ho);
+    const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const size_t coff = (size_t)(c >> 5) * 128 + (c & 31) * 2;               // byte offset of the hi halfs inside a pixel
+    const size_t pp = (size_t)C * 4;                                         // pixel pitch in bytes
+    const unsigned char* b = src + (size_t)m * H * W * pp + coff;
+    const unsigned char* p00 = b + ((size_t)y0 * W + x0) * pp; const unsigned char* p01 = b + ((size_t)y0 * W + x1) * pp;
+    const unsigned char* p10 = b + ((size_t)y1 * W + x0) * pp; const unsigned char* p11 = b + ((size_t)y1 * W + x1) * pp;
+    const omni_h8v h00 = *reinterpret_cast<const omni_h8v*>(p00), l00 = *reinterpret_cast<const omni_h8v*>(p00 + 64);
+    const omni_h8v h01 = *reinterpret_cast<const omni_h8v*>(p01), l01 = *reinterpret_cast<const omni_h8v*>(p01 + 64);
+    const omni_h8v h10 = *reinterpret_cast<const omni_h8v*>(p10), l10 = *reinterpret_cast<const omni_h8v*>(p10 + 64);
+    const omni_h8v h11 = *reinterpret_cast<const omni_h8v*>(p11), l11 = *reinterpret_cast<const omni_h8v*>(p11 + 64);
+    omni_h8v oh, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v00 = fmaf((float)l00[e], 4.8828125e-4f, (float)h00[e]), v01 = fmaf((float)l01[e], 4.8828125e-4f, (float)h01[e]);
+        const float v10 = fmaf((float)l10[e], 4.8828125e-4f, (float)h10[e]), v11 = fmaf((float)l11[e], 4.8828125e-4f, (float)h11[e]);
+        const float o = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        const _Float16 h = (fabsf(o) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)o;
+        oh[e] = h; ol[e] = (_Float16)((o - (float)h) * 2048.0f);
+    }
+    unsigned char* d = dst + (((size_t)m * Ho + oy) * Wo + ox) * pp + coff;
+    *reinterpret_cast<omni_h8v*>(d) = oh; *reinterpret_cast<omni_h8v*>(d + 64) = ol;
+}
+
 // x[m][hw][c] += y[m][c]            (token bias on layer4)
 __global__ __launch_bounds__(256) void add_hw_kernel(float* __restrict__ x, const float* __restrict__ y, size_t total, int HW, int C)
 {
@@ -379,8 +418,8 @@ int omni_maxpool3x3s2_sh(const void* src, void* dst, int M, int H, int W, int C,
 int omni_upsample_bilinear_sh(const void* src, void* dst, int M, int H, int W, int C, int Ho, int Wo, omni_stream_t stream)
 {
     if (C % 32) OMNI_FAIL(OMNI_ERR_INVALID, "SH tensors need C % 32 == 0");
-    hipLaunchKernelGGL(upsample_kernel<true>, dim3(nblk((size_t)M * Ho * Wo * C / 4)), dim3(256), 0, S_, src, dst, M, H, W, C, Ho, Wo,
-                       (float)H / (float)Ho, (float)W / (float)Wo);
+    hipLaunchKernelGGL(upsample_sh8_kernel, dim3(nblk((size_t)M * Ho * Wo * C / 8)), dim3(256), 0, S_, (const unsigned char*)src,
+                       (unsigned char*)dst, M, H, W, C, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_add_hw_sh(void* x, const float* y, int M, int HW, int C, omni_stream_t stream)

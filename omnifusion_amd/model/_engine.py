@@ -81,6 +81,8 @@ class Engine:
         W = {}
         w, b = self._fold(sd, "conv1", "bn1")                                    # stem: [147][64], k = (ky*7+kx)*3 + c
         W["stem.w"] = f(w.permute(2, 3, 1, 0).reshape(147, 64)); W["stem.b"] = f(b)
+        wk = torch.zeros((64, 3, 7, 8), dtype=torch.float64); wk[..., :7] = w                 # k = (c*7 + ky)*8 + kx, kx = 7 zero
+        W["stem.w16"] = split_weights_f16x3(torch.cat([wk.reshape(64, 168), torch.zeros((64, 24), dtype=torch.float64)], 1)).to(dev)
 
         def convbn(key, conv, bn):
             w, b = self._fold(sd, conv, bn)
@@ -230,8 +232,11 @@ class Engine:
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         conv1 = new(M, P2, P2, 64)
         sh = self.sh                                                # activations between the convolutions: SH or fp32 NHWC
-        _lib.check((lib.omni_stem_sh if sh else lib.omni_stem_f32)(_p(patches), _p(self.w["stem.w"]), _p(self.w["stem.b"]),
-                                                                    _p(conv1), M, P, self._s), "stem")
+        if sh and P % 32 == 0:
+            _lib.check(lib.omni_stem_sh_f16x3(_p(patches), _p(self.w["stem.w16"]), _p(self.w["stem.b"]), _p(conv1), M, P, self._s), "stem")
+        else:
+            _lib.check((lib.omni_stem_sh if sh else lib.omni_stem_f32)(_p(patches), _p(self.w["stem.w"]), _p(self.w["stem.b"]),
+                                                                        _p(conv1), M, P, self._s), "stem")
         x = new(M, P4, P4, 64)
         _lib.check((lib.omni_maxpool3x3s2_sh if sh else lib.omni_maxpool3x3s2_f32)(_p(conv1), _p(x), M, P2, P2, 64, self._s), "maxpool")
         feats = {}

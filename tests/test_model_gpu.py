@@ -137,6 +137,13 @@ def test_sh_elementwise_ops_match_f32():
     assert lib.omni_stem_f32(_p(src), _p(wt), _p(b), _p(o32), M, P, _stream()) == 0
     assert lib.omni_stem_sh(_p(src), _p(wt), _p(b), _p(osh), M, P, _stream()) == 0
     assert close(from_sh(osh), o32)
+    # the same stem as an implicit GEMM on the fp16 matrix cores (k = (c*7+ky)*8+kx, padded to 192)
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    wk = torch.zeros(64, 3, 7, 8); wk[..., :7] = wt.cpu().reshape(7, 7, 3, 64).permute(3, 2, 0, 1)
+    w16 = split_weights_f16x3(torch.cat([wk.reshape(64, 168), torch.zeros(64, 24)], 1)).to(DEV)
+    omm = torch.empty_like(o32)
+    assert lib.omni_stem_sh_f16x3(_p(src), _p(w16), _p(b), _p(omm), M, P, _stream()) == 0, lib.omni_last_error()
+    assert (from_sh(omm) - o32).abs().max().item() < 2e-5
     # maxpool / upsample on a 64-channel tensor
     x = torch.randn(3, 10, 12, 64, generator=g).to(DEV); xs = to_sh(x)
     mp32 = torch.empty(3, 5, 6, 64, device=DEV); mpsh = torch.empty_like(mp32)

@@ -127,10 +127,9 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 3>           // NST stages in flight (the step loop is unrolled by it)
 __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
 {
-    constexpr int NST = 3;                                      // stages in flight (the step loop is unrolled by it)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
     constexpr int APASS = BM / 32, BPASS = BN / 32, LPS = APASS + BPASS;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
@@ -246,13 +245,16 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
         ks_begin = blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
     }
     seek(ks_begin);
-    if (ks_begin < ks_end) issue(ks_begin, std::integral_constant<int, 0>());
-    if (ks_begin + 1 < ks_end) issue(ks_begin + 1, std::integral_constant<int, 1>());
+    [&]<int... S>(std::integer_sequence<int, S...>) {            // prologue: stages 0 .. NST-2 in flight
+        ((ks_begin + S < ks_end ? issue(ks_begin + S, std::integral_constant<int, S>()) : (void)0), ...);
+    }(std::make_integer_sequence<int, NST - 1>());
 
     auto step = [&](int ks, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (ks + 1 < ks_end) wait_vm<LPS>();                     // my pieces of stage ks have landed (those of ks+1 may fly)
-        else                 wait_vm<0>();
+        // my pieces of stage ks have landed when at most the NST-2 younger stages are in flight (near the end fewer were issued:
+        // a smaller count only waits longer, 0 is always safe)
+        if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
+        else                       wait_vm<0>();
         __builtin_amdgcn_s_barrier();                            // ... everybody's have; everybody is done reading stage ks-1
         asm volatile("" ::: "memory");
         const unsigned char* sl = lds + SLOT * STAGE;
@@ -281,20 +283,20 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);
                 }
-            if (kc == 0) {                                       // the stage after next, issued under the first half's matrix work
+            if (kc == 0) {                                       // stage ks+NST-1, issued under the first half's matrix work
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks + 2 < ks_end) issue(ks + 2, std::integral_constant<int, (SLOT + 2) % NST>());
+                if (ks + NST - 1 < ks_end) issue(ks + NST - 1, std::integral_constant<int, (SLOT + NST - 1) % NST>());
             }
         }
     };
     int ks = ks_begin;
-    for (; ks + 2 < ks_end; ks += 3) {                           // (no early exits inside: they would park the accumulators in VGPRs)
-        step(ks, std::integral_constant<int, 0>());
-        step(ks + 1, std::integral_constant<int, 1>());
-        step(ks + 2, std::integral_constant<int, 2>());
+    for (; ks + NST - 1 < ks_end; ks += NST) {                   // (no early exits inside: they would park the accumulators in VGPRs)
+        [&]<int... S>(std::integer_sequence<int, S...>) { (step(ks + S, std::integral_constant<int, S>()), ...); }
+        (std::make_integer_sequence<int, NST>());
     }
-    if (ks < ks_end) step(ks, std::integral_constant<int, 0>());
-    if (ks + 1 < ks_end) step(ks + 1, std::integral_constant<int, 1>());
+    [&]<int... S>(std::integer_sequence<int, S...>) {            // remainder: up to NST-1 steps
+        ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
+    }(std::make_integer_sequence<int, NST - 1>());
 
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
 #pragma unroll
@@ -602,11 +604,11 @@ __global__ __launch_bounds__(256) void sh_to_f32_kernel(const void* __restrict__
     *reinterpret_cast<f4v*>(dst + i * 4) = sh_join4(*reinterpret_cast<const h4v*>(sp), *reinterpret_cast<const h4v*>(sp + 64));
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 3>
 void launch_sh(const ShConvArgs& a, hipStream_t s)
 {
     const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
 }
 }  // namespace
 
@@ -656,6 +658,7 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s);
     else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s);
     else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
+    else if (rows <= 512 && ksteps >= 8 && !getenv("OMNI_CONV_NODEEP")) launch_sh<64, 64, 2, 2, 6>(a, s);   // a few blocks only (the transformer GEMMs): latency-bound, keep 5 stages in flight
     else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
     if (a.splitk > 1) {

@@ -9,16 +9,14 @@ python - "$f" <<'PY'
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# group consecutive runs of the same (kernel, grid): report the mean of the last 20 of each run
-runs = []
+# aggregate by (kernel, grid): mean of the last 20 dispatches of each
+agg = collections.OrderedDict()
 for r in rows:
     n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])[:60]
-    key = (n, r["Grid_Size_X"], r["Grid_Size_Y"])
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if "conv" not in n and "reduce" not in n: continue
-    if runs and runs[-1][0] == key: runs[-1][1].append(d)
-    else: runs.append((key, [d]))
-for key, ds in runs:
+    key = (n, r["Grid_Size_X"], r["Grid_Size_Y"])
+    agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for key, ds in agg.items():
     if len(ds) >= 10:
         tail = ds[-20:]
         print(f"{key[0]:62s} grid={key[1]:>9s}x{key[2]:<3s} n={len(ds):3d} mean={sum(tail)/len(tail):7.1f} us  min={min(tail):7.1f}")

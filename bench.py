@@ -116,7 +116,7 @@ def main():
         ev[k][0].record()
         patches = equi2pers_patches(rgb, FOV, NROWS, (128, 128), layout=LAY)
         ev[k][1].record()
-        a, c = eng.network(patches, eng.w["point_feat"], B, True)
+        a, c = net.network(patches, B, True)
         ev[k][2].record()
         depth = eng.blend(a, c, (ERP_H, ERP_W))
         ev[k][3].record()
@@ -164,7 +164,8 @@ def main():
                                "single-pass spherical_fusion forward (confidence=True) at patch size 128 — the only size the "
                                "reference network exists at (SURVEY 0.1); random-init weights (seed 42); inputs resident in HBM; "
                                "resample pair at 18x256^2 reported in roofline_resample",
-                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}"},
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
+                   "streams_per_gpu": net.LANES if B >= 2 * net.LANES else 1},
         "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3},
         "roofline": {"bound": "mfma",
                      "kernel": ("network section (conv_sh_kernel / conv3x3_halo_sh_kernel dominant" if f16x3 else

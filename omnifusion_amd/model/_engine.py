@@ -59,6 +59,13 @@ class Engine:
     def sh(self):
         return self.precision == "f16x3"
 
+    def lane(self):
+        """A second execution context over the SAME packed weights (own split-K workspace and per-call state): the model
+        runs the two halves of a batch on two streams so that one half's kernel tails overlap the other half's work."""
+        e = Engine(self.nrows, self.npatches, self.patch_size, self.fov, self.iterative)
+        e.precision, e.w, e.device, e.head_bias = self.precision, self.w, self.device, getattr(self, "head_bias", None)
+        return e
+
     # ------------------------------------------------------------------ packing
     @staticmethod
     def _fold(sd, conv, bn):
@@ -219,7 +226,7 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ network over the patch batch
-    def network(self, patches, point_feat, bs, confidence):
+    def network(self, patches, point_feat, bs, confidence, out=None):
         """patches: planar [bs, N, 3, P, P]; point_feat: NHWC [N or bs*N, P/4, P/4, 64].
         Returns (a, c) planar [bs, N, 1, P, P]: a = relu(pred) (* conf), c = sigmoid(weight) or None."""
         lib = _lib.load()
@@ -303,8 +310,7 @@ class Engine:
         x = self._conv(x, "de_conv3_1", M, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1, C2=64)
         up = self._up(x, M, P2, P2, 32, P, P)
         x = self._conv(up, "de_conv4_0", M, P, P, 32, 32, 3, 1, 1, ACT_RELU, out_f32=True)
-        a = new(bs, N, 1, P, P)
-        c = new(bs, N, 1, P, P) if confidence else None
+        a, c = out if out is not None else (new(bs, N, 1, P, P), new(bs, N, 1, P, P) if confidence else None)
         _lib.check(lib.omni_heads_f32(_p(x), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]),
                                       ctypes.c_float(self.head_bias[1]), _p(a), _p(c), M, P, 1 if confidence else 0, self._s), "heads")
         self.last = {"de_conv4_0": x, "layer4": layer4}

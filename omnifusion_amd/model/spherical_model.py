@@ -92,5 +92,46 @@ class spherical_fusion:
         bs, _, H, W = rgb.shape
         with torch.cuda.device(rgb.device):
             patches = equi2pers_patches(rgb, self.fov, self.nrows, self.patch_size, layout=_lib.LAYOUT_BNCHW)   # :243
-            a, c = e.network(patches, e.w["point_feat"], bs, confidence)                                        # :245-306
+            a, c = self.network(patches, bs, confidence)                                                        # :245-306
             return e.blend(a, c, (H, W))                                                                        # :307-313
+
+    def network(self, patches, bs, confidence):
+        """planar patches [bs,N,3,P,P] -> (pred * conf, conf) planes [bs,N,1,P,P] (the part of forward between the two resamplers)"""
+        e = self._eng
+        if bs < 2 * self.LANES or self.LANES < 2:
+            return e.network(patches, e.w["point_feat"], bs, confidence)
+        return self._network_lanes(patches, bs, confidence)
+
+    # Two halves of the batch on two streams.  Every layer of the network is ONE kernel whose last blocks leave most of the
+    # chip idle (the deep layers are 2.25 blocks per CU at 8 panoramas); with two independent half-batch chains in flight
+    # the scheduler fills one chain's tail with the other chain's blocks.  Results are bit-identical to the single-stream
+    # path (split-K is planned for a nominal batch, every output element is one k-ordered chain).  OMNI_LANES=1 disables.
+    import os as _os
+    LANES = int(_os.environ.get("OMNI_LANES", "2"))
+
+    def _network_lanes(self, patches, bs, confidence):
+        e = self._eng
+        if getattr(self, "_lanes", None) is None or self._lanes[0][0].w is not e.w:
+            self._lanes = [(e, None)] + [(e.lane(), torch.cuda.Stream(device=patches.device)) for _ in range(self.LANES - 1)]
+        N, P = self.npatches, e.patch_size[0]
+        a = torch.empty((bs, N, 1, P, P), dtype=torch.float32, device=patches.device)
+        c = torch.empty_like(a) if confidence else None
+        cur = torch.cuda.current_stream(patches.device)
+        fork = cur.record_event()
+        per = (bs + self.LANES - 1) // self.LANES
+        joins = []
+        for k, (eng, stream) in enumerate(self._lanes):
+            lo, hi = k * per, min(bs, (k + 1) * per)
+            if lo >= hi:
+                break
+            out = (a[lo:hi], c[lo:hi] if confidence else None)
+            if stream is None:
+                eng.network(patches[lo:hi], e.w["point_feat"], hi - lo, confidence, out=out)
+            else:
+                stream.wait_event(fork)
+                with torch.cuda.stream(stream):
+                    eng.network(patches[lo:hi], e.w["point_feat"], hi - lo, confidence, out=out)
+                    joins.append(stream.record_event())
+        for ev in joins:
+            cur.wait_event(ev)
+        return a, c

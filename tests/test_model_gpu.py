@@ -232,6 +232,25 @@ def test_single_pass_model_golden():
     assert torch.equal(net(rgb[1:2], confidence=True), out[1:2])
 
 
+def test_two_stream_lanes_are_bit_identical():
+    """batches of >= 4 panoramas run as two half-batches on two streams (spherical_model.py `_network_lanes`): same bits as
+    the single-stream path, also through graph capture"""
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rgb = torch.rand((5, 3, 64, 128), generator=torch.Generator().manual_seed(11)).to(DEV)
+    assert spherical_fusion.LANES == 2
+    two = net(rgb, confidence=True).clone()
+    try:
+        spherical_fusion.LANES = 1
+        one = net(rgb, confidence=True).clone()
+    finally:
+        spherical_fusion.LANES = 2
+    assert torch.equal(one, two)
+    run = net.graphed(rgb, confidence=True)
+    assert torch.equal(run(rgb), two)
+
+
 def test_iterative_model_golden():
     _, spherical_fusion_it, make_state_dict = _nets()
     g = golden("G7_model_iterative")

@@ -435,6 +435,7 @@ int plan_splitk(long long rows, int Cout, int ksteps)
     long long s = (640 + blocks - 1) / blocks;
     if (s > ksteps / 4) s = ksteps / 4;
     if (s > 32) s = 32;
+    if (const char* e = getenv("OMNI_SPLITK_MAX")) { const long long cap = atoi(e); if (s > cap) s = cap; }   // tuning hook
     return s < 2 ? 1 : (int)s;
 }
 }  // namespace

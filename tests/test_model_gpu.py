@@ -150,10 +150,11 @@ def test_sh_elementwise_ops_match_f32():
     assert lib.omni_maxpool3x3s2_f32(_p(x), _p(mp32), 3, 10, 12, 64, _stream()) == 0
     assert lib.omni_maxpool3x3s2_sh(_p(xs), _p(mpsh), 3, 10, 12, 64, _stream()) == 0
     assert close(from_sh(mpsh), mp32)
-    up32 = torch.empty(3, 20, 24, 64, device=DEV); upsh = torch.empty_like(up32)
-    assert lib.omni_upsample_bilinear_f32(_p(x), _p(up32), 3, 10, 12, 64, 20, 24, _stream()) == 0
-    assert lib.omni_upsample_bilinear_sh(_p(xs), _p(upsh), 3, 10, 12, 64, 20, 24, _stream()) == 0
-    assert close(from_sh(upsh), up32)
+    for (Ho, Wo) in ((20, 24), (15, 30)):                       # exact 2x (fast path) and a generic ratio
+        up32 = torch.empty(3, Ho, Wo, 64, device=DEV); upsh = torch.empty_like(up32)
+        assert lib.omni_upsample_bilinear_f32(_p(x), _p(up32), 3, 10, 12, 64, Ho, Wo, _stream()) == 0
+        assert lib.omni_upsample_bilinear_sh(_p(xs), _p(upsh), 3, 10, 12, 64, Ho, Wo, _stream()) == 0
+        assert close(from_sh(upsh), up32)
     # broadcast adds
     y = torch.randn(3, 64, generator=g).to(DEV)
     a32, ash = x.clone(), to_sh(x)

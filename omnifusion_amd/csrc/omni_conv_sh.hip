@@ -128,10 +128,12 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
 }
 
 template <int BM, int BN, int WM, int WN, int NST = 3>           // NST stages in flight (the step loop is unrolled by it)
-__global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
+__global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
 {
+    constexpr int NW = WM * WN, RPP = 8 * NW;                   // waves per block; tile rows covered by one DMA pass of the block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
-    constexpr int APASS = BM / 32, BPASS = BN / 32, LPS = APASS + BPASS;
+    constexpr int APASS = BM / RPP, BPASS = BN / RPP, LPS = APASS + BPASS;
+    static_assert(APASS >= 1 && BPASS >= 1, "a tile side must cover at least one DMA pass");
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
@@ -144,16 +146,16 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
     const int G1 = a.C1 >> 5, G2 = a.C2 >> 5, G = G1 + G2;
     const int ksteps = a.KH * a.KW * G;
 
-    // ---- DMA geometry: instruction j of a tile covers LDS row pairs 4j .. 4j+3; wave w issues j = w, w+4, ...  Lane i
+    // ---- DMA geometry: instruction j of a tile covers LDS row pairs 4j .. 4j+3; wave w issues j = w, w+NW, ...  Lane i
     // owns slot g' = i & 15 of pair d = 4j + (i >> 4), i.e. fetches piece g = g' ^ (d & 15) -> row 2d + (g >> 3), 16-byte
-    // piece g & 7.  (d & 15 does not depend on the pass, so the lane's piece is fixed and its row advances by 32 per pass.)
+    // piece g & 7.  (d & 15 does not depend on the pass, so the lane's piece is fixed and its row advances by 8 NW per pass.)
     const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
     const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
     int pix[APASS];                                              // pixel index of the (possibly padded) window origin
     unsigned vmask[APASS];                                       // bit (ky*KW+kx): tap inside the image
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-        const int r = row0 + rl + 32 * i;
+        const int r = row0 + rl + RPP * i;
         vmask[i] = 0; pix[i] = 0;
         if (r < a.rows) {
             const int hw = a.Ho * a.Wo;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
     const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * ksteps * 128);
     int wbase[BPASS];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) wbase[i] = (col0 + rl + 32 * i) * ksteps * 128 + pc16;
+    for (int i = 0; i < BPASS; ++i) wbase[i] = (col0 + rl + RPP * i) * ksteps * 128 + pc16;
 
     // ---- issue side.  The K order is (tap, source, 32-channel group); everything that depends on the lane is recomputed
     // only when (tap, source) changes — voff[i] = byte offset of this lane's piece for group 0, or out of range for a tap
@@ -205,13 +207,13 @@ __global__ __launch_bounds__(256) void conv_sh_kernel(ShConvArgs a)
         const int so = f_gl * 128;
         if (f_src) {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) dma16(rs2, sb + i * 4096, voff[i], so);
+            for (int i = 0; i < APASS; ++i) dma16(rs2, sb + i * (1024 * NW), voff[i], so);
         } else {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * 4096, voff[i], so);
+            for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * (1024 * NW), voff[i], so);
         }
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * 4096, wbase[i], ks * 128);
+        for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * (1024 * NW), wbase[i], ks * 128);
         if (++f_gl == f_gn) {
             f_gl = 0;
             if (f_src == 0 && G2 > 0) { f_src = 1; f_gn = G2; }
@@ -608,7 +610,7 @@ template <int BM, int BN, int WM, int WN, int NST = 3>
 void launch_sh(const ShConvArgs& a, hipStream_t s)
 {
     const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(64 * WM * WN), 0, s, a);
 }
 }  // namespace
 
@@ -658,6 +660,8 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s);
     else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s);
     else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
+    else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s);            // 8 waves
+    else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
     else if (rows <= 512 && ksteps >= 8 && !getenv("OMNI_CONV_NODEEP")) launch_sh<64, 64, 2, 2, 6>(a, s);   // a few blocks only (the transformer GEMMs): latency-bound, keep 5 stages in flight
     else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());

@@ -296,42 +296,61 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 constexpr int HT = 16, HPITCH = 36;
 __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x, const float* __restrict__ w /*[2][9][32]*/,
                                                     float bp, float bw, float* __restrict__ outa, float* __restrict__ outc,
-                                                    int M, int P, int conf)
+                                                    int M, int P, int conf, int ntiles)
 {
+    // persistent blocks: the next tile's 18x18x32 halo is in flight in registers (11 x 16 bytes per thread) while the
+    // current tile's 2 x 288 multiply-adds per pixel run out of LDS
     __shared__ __attribute__((aligned(16))) float tile[(HT + 2) * (HT + 2) * HPITCH];
+    constexpr int NLD = ((HT + 2) * (HT + 2) * 8 + 255) / 256;
     const int tiles = (P + HT - 1) / HT;
-    const int m = blockIdx.x / (tiles * tiles), tt = blockIdx.x % (tiles * tiles);
-    const int y0 = (tt / tiles) * HT - 1, x0 = (tt % tiles) * HT - 1;
-    for (int i = threadIdx.x; i < (HT + 2) * (HT + 2) * 8; i += 256) {
-        const int px = i >> 3, q = i & 7;
-        const int iy = y0 + px / (HT + 2), ix = x0 + px % (HT + 2);
-        f4v v = (f4v)(0.0f);
-        if ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
-            v = *reinterpret_cast<const f4v*>(x + (((size_t)m * P + iy) * P + ix) * 32 + q * 4);
-        *reinterpret_cast<f4v*>(tile + px * HPITCH + q * 4) = v;
-    }
-    __syncthreads();
-    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
-    float ap = bp, aw = bw;
+    f4v pre[NLD];
+    auto fetch = [&](int tid) {
+        const int m = tid / (tiles * tiles), tt = tid % (tiles * tiles);
+        const int y0 = (tt / tiles) * HT - 1, x0 = (tt % tiles) * HT - 1;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float* px = tile + ((ly + ky) * (HT + 2) + lx + kx) * HPITCH;
-            const float* w0 = w + (ky * 3 + kx) * 32; const float* w1 = w0 + 288;
-#pragma unroll
-            for (int c = 0; c < 32; c += 4) {
-                const f4v v = *reinterpret_cast<const f4v*>(px + c);
-                ap = fmaf(v.x, w0[c], ap); ap = fmaf(v.y, w0[c + 1], ap); ap = fmaf(v.z, w0[c + 2], ap); ap = fmaf(v.w, w0[c + 3], ap);
-                aw = fmaf(v.x, w1[c], aw); aw = fmaf(v.y, w1[c + 1], aw); aw = fmaf(v.z, w1[c + 2], aw); aw = fmaf(v.w, w1[c + 3], aw);
-            }
+        for (int k = 0; k < NLD; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int px = i >> 3, q = i & 7;
+            const int iy = y0 + px / (HT + 2), ix = x0 + px % (HT + 2);
+            pre[k] = (f4v)(0.0f);
+            if (i < (HT + 2) * (HT + 2) * 8 && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+                pre[k] = *reinterpret_cast<const f4v*>(x + (((size_t)m * P + iy) * P + ix) * 32 + q * 4);
         }
-    const int oy = y0 + 1 + ly, ox = x0 + 1 + lx;
-    if (oy < P && ox < P) {
-        const size_t i = ((size_t)m * P + oy) * P + ox;
-        const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
-        outa[i] = conf ? pr * cf : pr;
-        if (outc) outc[i] = cf;
+    };
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    int tid = blockIdx.x;
+    if (tid < ntiles) fetch(tid);
+    for (; tid < ntiles; tid += gridDim.x) {
+        __syncthreads();                                          // the previous tile's taps are done
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < (HT + 2) * (HT + 2) * 8) *reinterpret_cast<f4v*>(tile + (i >> 3) * HPITCH + (i & 7) * 4) = pre[k];
+        }
+        __syncthreads();
+        if (tid + (int)gridDim.x < ntiles) fetch(tid + gridDim.x);
+        float ap = bp, aw = bw;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* px = tile + ((ly + ky) * (HT + 2) + lx + kx) * HPITCH;
+                const float* w0 = w + (ky * 3 + kx) * 32; const float* w1 = w0 + 288;
+#pragma unroll
+                for (int c = 0; c < 32; c += 4) {
+                    const f4v v = *reinterpret_cast<const f4v*>(px + c);
+                    ap = fmaf(v.x, w0[c], ap); ap = fmaf(v.y, w0[c + 1], ap); ap = fmaf(v.z, w0[c + 2], ap); ap = fmaf(v.w, w0[c + 3], ap);
+                    aw = fmaf(v.x, w1[c], aw); aw = fmaf(v.y, w1[c + 1], aw); aw = fmaf(v.z, w1[c + 2], aw); aw = fmaf(v.w, w1[c + 3], aw);
+                }
+            }
+        const int m = tid / (tiles * tiles), tt = tid % (tiles * tiles);
+        const int oy = (tt / tiles) * HT + ly, ox = (tt % tiles) * HT + lx;
+        if (oy < P && ox < P) {
+            const size_t i = ((size_t)m * P + oy) * P + ox;
+            const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
+            outa[i] = conf ? pr * cf : pr;
+            if (outc) outc[i] = cf;
+        }
     }
 }
 
@@ -466,7 +485,8 @@ int omni_heads_f32(const float* x, const float* w, float bias_pred, float bias_w
                    int M, int P, int confidence, omni_stream_t stream)
 {
     const int ht = (P + HT - 1) / HT;
-    hipLaunchKernelGGL(heads_kernel, dim3(M * ht * ht), dim3(256), 0, S_, x, w, bias_pred, bias_weight, out_a, out_c, M, P, confidence);
+    const int ntiles = M * ht * ht;
+    hipLaunchKernelGGL(heads_kernel, dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, S_, x, w, bias_pred, bias_weight, out_a, out_c, M, P, confidence, ntiles);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_mlp_points_f32(const float* xyz, const float* depth, const float* w1, const float* b1, const float* w2,

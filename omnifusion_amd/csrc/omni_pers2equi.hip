@@ -160,35 +160,49 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
         }
         float l1 = 0.0f;
         unsigned long long m = cmask;
-        while (m) {                                            // wave-uniform loop over candidate patches
-            const int n = __builtin_ctzll(m);
+        // wave-uniform loop over candidate patches, TWO per trip: both patches' tap loads are in flight before the first
+        // is consumed (the blend is a chain of dependent memory round trips: candidate mask -> patch constants -> taps)
+        while (m) {
+            const int n0 = __builtin_ctzll(m);
             m &= m - 1;
-            Taps t;
-            p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
-            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);  // all >= 0 after the threshold
-            l1 += wsum;
-            const bool any = inside && wsum > 0.0f;
-            if (any) {
-                unsigned o0, o1, dx = 0; int sel = 0;
-                if (XS1) {
-                    const int xb = min(t.x0, a.pw - 2);
-                    sel = t.x0 - xb;
-                    o0 = (unsigned)n * sN + (unsigned)t.y0 * sY + (unsigned)xb;
-                    o1 = (unsigned)n * sN + (unsigned)t.y1 * sY + (unsigned)xb;
-                } else {
-                    o0 = (unsigned)n * sN + (unsigned)t.y0 * sY + (unsigned)t.x0 * sX;
-                    o1 = (unsigned)n * sN + (unsigned)t.y1 * sY + (unsigned)t.x0 * sX;
-                    dx = (unsigned)(t.x1 - t.x0) * sX;
-                }
+            const bool two = m != 0ull;
+            const int n1 = two ? __builtin_ctzll(m) : n0;
+            if (two) m &= m - 1;
+            Taps t[2];
+            p2e_taps(a, n0, rt.x, rt.y, ct.x, ct.y, t[0]);
+            p2e_taps(a, n1, rt.x, rt.y, ct.x, ct.y, t[1]);
+            if (!two) { t[1].wa = 0.0f; t[1].wb = 0.0f; t[1].wc = 0.0f; t[1].wd = 0.0f; }
+            unsigned o0[2], o1[2], dx[2]; int sel[2]; bool any[2];
 #pragma unroll
-                for (int k = 0; k < PL; ++k) {
-                    const int p = p0 + k;
-                    if (p < planes) {
-                        const size_t base = CONF ? (size_t)p * (size_t)a.sB
-                                                 : (size_t)(p / a.C) * (size_t)a.sB + (size_t)(p % a.C) * (size_t)a.sC;
-                        acc[k] += p2e_fetch<T, XS1>(pers + base, o0, o1, dx, sel, t);
-                        if (CONF) acc2[k] += p2e_fetch<T, XS1>(pers2 + base, o0, o1, dx, sel, t);
-                    }
+            for (int u = 0; u < 2; ++u) {
+                const int n = u ? n1 : n0;
+                const float wsum = (t[u].wa + t[u].wb) + (t[u].wc + t[u].wd);   // all >= 0 after the threshold
+                l1 += wsum;
+                any[u] = inside && wsum > 0.0f;
+                dx[u] = 0; sel[u] = 0;
+                if (XS1) {
+                    const int xb = min(t[u].x0, a.pw - 2);
+                    sel[u] = t[u].x0 - xb;
+                    o0[u] = (unsigned)n * sN + (unsigned)t[u].y0 * sY + (unsigned)xb;
+                    o1[u] = (unsigned)n * sN + (unsigned)t[u].y1 * sY + (unsigned)xb;
+                } else {
+                    o0[u] = (unsigned)n * sN + (unsigned)t[u].y0 * sY + (unsigned)t[u].x0 * sX;
+                    o1[u] = (unsigned)n * sN + (unsigned)t[u].y1 * sY + (unsigned)t[u].x0 * sX;
+                    dx[u] = (unsigned)(t[u].x1 - t[u].x0) * sX;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PL; ++k) {
+                const int p = p0 + k;
+                if (p < planes) {
+                    const size_t base = CONF ? (size_t)p * (size_t)a.sB
+                                             : (size_t)(p / a.C) * (size_t)a.sB + (size_t)(p % a.C) * (size_t)a.sC;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (any[u]) {
+                            acc[k] += p2e_fetch<T, XS1>(pers + base, o0[u], o1[u], dx[u], sel[u], t[u]);
+                            if (CONF) acc2[k] += p2e_fetch<T, XS1>(pers2 + base, o0[u], o1[u], dx[u], sel[u], t[u]);
+                        }
                 }
             }
         }

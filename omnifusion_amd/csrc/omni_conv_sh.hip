@@ -82,6 +82,7 @@ struct ShConvArgs {
     int rows;                                // M*Ho*Wo
     int dst_sh;
     int res_f32;                             // residual is plain fp32 NHWC instead of SH
+    int dbg;                                 // OMNI_CONV_DBG (tuning): 4 = skip the epilogue
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
 };
 
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
     }(std::make_integer_sequence<int, NST - 1>());
 
+    if (a.dbg & 4) return;
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -333,23 +335,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
 // wave w owns image row y0+w (32 pixels = one MFMA column tile), its pixel fragment for tap (ky,kx) is the same LDS image
 // shifted by ky rows and kx pixels.  The weights arrive one kernel row (3 taps) at a time through a double buffer: the
 // next row's DMA is in flight under the 18*BN/32 MFMAs of the current one.  Requires W % 32 == 0, H % 4 == 0.
-constexpr int HT_H = 4, HT_W = 32, HPW = HT_W + 2, HPX = (HT_H + 2) * HPW;      // 204 halo pixels
-constexpr int HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;       // 26 DMA instructions, 26 KiB
+constexpr int HT_W = 32, HPW = HT_W + 2;
 
-template <int BN>
-__global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
+// TH = image rows per block = waves per block (4: 6x34 halo, 26 KiB; 8: 10x34 halo, 43 KiB, half the weight traffic per pixel)
+template <int BN, int TH>
+__global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 {
-    constexpr int TN = BN / 32;
-    constexpr int APASS = (HA_INSTR + 3) / 4, BROWS = 3 * BN, BPASS = BROWS / 32, B_BYTES = BROWS * 128;
+    constexpr int TN = BN / 32, NW = TH, RPP = 8 * NW;
+    constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
+    constexpr int APASS = (HA_INSTR + NW - 1) / NW, BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[HA_BYTES + 2 * B_BYTES];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / HT_H;
+    const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / TH;
     int bid = blockIdx.x;
     const int tile_n = bid % ntn; bid /= ntn;
     const int tx = bid % tw; bid /= tw;
     const int ty = bid % th; const int m = bid / th;
-    const int y0 = ty * HT_H, x0 = tx * HT_W, col0 = tile_n * BN;
+    const int y0 = ty * TH, x0 = tx * HT_W, col0 = tile_n * BN;
     const int G1 = a.C1 >> 5, G = (a.C1 + a.C2) >> 5, ksteps = 9 * G;
 
     // DMA geometry (as in conv_sh_kernel): lane -> row rl + 32*pass of the region, 16-byte piece pc16/16
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
     int apix[APASS];                                              // image pixel index of halo pixel rl + 32*i, or -1
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-        const int p = rl + 32 * i;
+        const int p = rl + RPP * i;
         const int hy = p / HPW, hx = p - hy * HPW;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         apix[i] = (p < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (m * a.H + iy) * a.W + ix : -1;
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
     int wbase[BPASS];                                             // weight row (kx, co) = row rl + 32*i of a kernel-row stage
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-        const int r = rl + 32 * i, kx = r / BN, co = r - kx * BN;
-        wbase[i] = ((col0 + co) * ksteps + kx * G) * 128 + pc16;
+        const int r = rl + RPP * i, kx = r / BN, co = r - kx * BN;
+        wbase[i] = r < BROWS ? ((col0 + co) * ksteps + kx * G) * 128 + pc16 : (int)0x80000000;
     }
     const rsrc_t rs1 = make_rsrc(a.src1, (size_t)a.M * a.H * a.W * a.C1 * 4);
     const rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? (size_t)a.M * a.H * a.W * a.C2 * 4 : 0);
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
         unsigned char* sb = lds + wave * 1024;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            if (wave + 4 * i < HA_INSTR) {
+            if (wave + NW * i < HA_INSTR) {
                 const int off = apix[i] >= 0 ? apix[i] * cs4 + soff : (int)0x80000000;
-                if (first) dma16(rs1, sb + i * 4096, off, 0);
-                else       dma16(rs2, sb + i * 4096, off, 0);
+                if (first) dma16(rs1, sb + i * (1024 * NW), off, 0);
+                else       dma16(rs2, sb + i * (1024 * NW), off, 0);
             }
         }
     };
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_sh_kernel(ShConvArgs a)
         unsigned char* sb = lds + HA_BYTES + buf * B_BYTES + wave * 1024;
         const int soff = (ky * 3 * G + g) * 128;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + i * 4096, wbase[i], soff);
+        for (int i = 0; i < BPASS; ++i)
+            if (wave + NW * i < BROWS / 8) dma16(rsw, sb + i * (1024 * NW), wbase[i], soff);
     };
 
     // pixel fragment offsets of the nine taps: halo pixel p = (wave+ky)*34 + (lane&31) + kx, row pair d = p >> 1,
@@ -631,6 +635,7 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: bad shape (kernels up to 3x3)");
     ShConvArgs a;
     a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh; a.res_f32 = (fmt >> 1) & 1;
+    { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
     a.M = M; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
@@ -647,10 +652,17 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
     a.splitk = S > 1 ? S : 1; a.ws = ws;
     hipStream_t s = (hipStream_t)stream;
-    if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % HT_H == 0 && !getenv("OMNI_CONV_NOHALO")) {
-        const int grid = M * (H / HT_H) * (W / HT_W);
-        if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
-        else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);
+    if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % 4 == 0 && !getenv("OMNI_CONV_NOHALO")) {
+        const char* he = getenv("OMNI_CONV_HALO_TH");
+        const int th = (H % 8 == 0 && (he ? atoi(he) == 8 : false)) ? 8 : 4;
+        const int grid = M * (H / th) * (W / HT_W);
+        if (th == 8) {
+            if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 8>), dim3(grid * (Cout / 64)), dim3(512), 0, s, a);
+            else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 8>), dim3(grid * (Cout / 32)), dim3(512), 0, s, a);
+        } else {
+            if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
+            else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);
+        }
         OMNI_HIP(hipGetLastError());
         return OMNI_OK;
     }

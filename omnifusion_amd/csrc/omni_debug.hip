@@ -66,3 +66,37 @@ extern "C" int omni_debug_dma_probe(const float* src, unsigned bytes, const int*
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
+
+// LDS-DMA fill rate: every wave streams 1-KiB pieces from an L2-resident buffer into its own LDS window
+namespace {
+template <int LDSKB>
+__global__ __launch_bounds__(256) void dma_rate_kernel(const float* src, unsigned bytes, int iters, float* sink)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char buf[LDSKB * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, bytes, 0x00020000);
+    unsigned char* my = buf + wave * 8192;
+    int off = ((blockIdx.x * 4 + wave) * 8192) % (bytes - 8192) & ~1023;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(my + p * 1024), 16, off + p * 1024 + lane * 16, 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        off = (off + 65536) % (bytes - 8192) & ~1023;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sink && threadIdx.x == 0 && buf[0] == 77 && buf[1] == 78) sink[0] = 1.0f;
+}
+}  // namespace
+
+extern "C" int omni_debug_dma_rate(const float* src, unsigned bytes, int iters, int blocks, int ldskb, float* sink, omni_stream_t stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (ldskb <= 32)      hipLaunchKernelGGL(dma_rate_kernel<32>, dim3(blocks), dim3(256), 0, s, src, bytes, iters, sink);
+    else if (ldskb <= 48) hipLaunchKernelGGL(dma_rate_kernel<48>, dim3(blocks), dim3(256), 0, s, src, bytes, iters, sink);
+    else                  hipLaunchKernelGGL(dma_rate_kernel<80>, dim3(blocks), dim3(256), 0, s, src, bytes, iters, sink);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

@@ -241,17 +241,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         void* __restrict__ out, int N, float scale, int qs, int kvs, int vo)
 {
     __shared__ float ks[64][129];
-    __shared__ float vs[64][128];
+    __shared__ __attribute__((aligned(16))) float vs[64][128];
     __shared__ float ps[4][64];
     const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    for (int i = t; i < N * 128; i += 256) {
-        const int j = i >> 7, d = i & 127;
+    for (int i = t; i < N * 32; i += 256) {                       // 16-byte loads of K and V rows
+        const int j = i >> 5, d = (i & 31) * 4;
         const float* row = kv + (size_t)(b * N + j) * kvs + h * 128 + d;
-        ks[j][d] = row[0]; vs[j][d] = row[vo];
+        const f4v kk = *reinterpret_cast<const f4v*>(row), vv = *reinterpret_cast<const f4v*>(row + vo);
+        ks[j][d] = kk.x; ks[j][d + 1] = kk.y; ks[j][d + 2] = kk.z; ks[j][d + 3] = kk.w;
+        *reinterpret_cast<f4v*>(&vs[j][d]) = vv;
     }
     __syncthreads();
-    for (int i = wave; i < N; i += 4) {
+    // blockIdx.y = group of TPB query tokens (one per wave and trip): the few (panorama, head) pairs alone would leave
+    // most CUs idle and every block walking all N tokens serially
+    constexpr int TPB = 4;
+    for (int i = blockIdx.y * TPB + wave; i < min(N, (int)(blockIdx.y + 1) * TPB); i += 4) {
         const float* qi = q + (size_t)(b * N + i) * qs + h * 128;
         float s = -INFINITY;
         if (lane < N) {
@@ -462,7 +467,7 @@ int omni_layernorm512_sh(const float* x, const float* g, const float* b, void* y
 int omni_attention_qkv_sh(const float* qkv, void* out, int B, int N, omni_stream_t stream)
 {
     if (N > 64) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_attention: at most 64 tokens");
-    hipLaunchKernelGGL(attention_kernel<true>, dim3(B * 4), dim3(256), 0, S_, qkv, qkv + 512, out, N, 0.08838834764831845f, 1536, 1536, 512);
+    hipLaunchKernelGGL(attention_kernel<true>, dim3(B * 4, (N + 3) / 4), dim3(256), 0, S_, qkv, qkv + 512, out, N, 0.08838834764831845f, 1536, 1536, 512);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream)
@@ -478,7 +483,7 @@ int omni_layernorm512_f32(const float* x, const float* g, const float* b, float*
 int omni_attention_f32(const float* q, const float* kv, float* out, int B, int N, omni_stream_t stream)
 {
     if (N > 64) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_attention: at most 64 tokens");
-    hipLaunchKernelGGL(attention_kernel<false>, dim3(B * 4), dim3(256), 0, S_, q, kv, (void*)out, N, 0.08838834764831845f /* 128^-1/2 */, 512, 1024, 512);
+    hipLaunchKernelGGL(attention_kernel<false>, dim3(B * 4, (N + 3) / 4), dim3(256), 0, S_, q, kv, (void*)out, N, 0.08838834764831845f /* 128^-1/2 */, 512, 1024, 512);
     OMNI_HIP(hipGetLastError()); return OMNI_OK;
 }
 int omni_heads_f32(const float* x, const float* w, float bias_pred, float bias_weight, float* out_a, float* out_c,

@@ -154,6 +154,17 @@ def main():
     bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * 4
     gbs_pair = (bytes_e2p + bytes_p2e) / (r_e2p + r_p2e) / 1e9
 
+    # ---- BASELINE cfg 2 as written (ONE panorama per forward): latency-bound, reported next to the batched figure
+    one = rgb[:1].contiguous()
+    for _ in range(3):
+        net(one, confidence=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        net(one, confidence=True)
+    torch.cuda.synchronize()
+    b1_ms = (time.perf_counter() - t1) / 10 * 1e3
+
     out = {
         "metric": "panoramas/sec at 512x1024 ERP, N=18 256^2 patches; equi2pers+pers2equi GB/s vs HBM peak",
         "value": world * B * args.steps / dt, "unit": "panoramas/s",
@@ -167,6 +178,8 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
                    "streams_per_gpu": net.LANES if B >= 2 * net.LANES else 1},
         "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3},
+        "batch1": {"ms_per_forward": b1_ms, "panoramas_per_s": 1e3 / b1_ms,
+                   "note": "BASELINE cfg 2 literally: one 512x1024 panorama per forward on this GPU (latency of ~150 dependent launches)"},
         "roofline": {"bound": "mfma",
                      "kernel": ("network section (conv_sh_kernel / conv3x3_halo_sh_kernel dominant" if f16x3 else
                                 "network section (conv_igemm_f32_kernel<...> dominant") + "; includes the stem/pool/upsample/LN/"

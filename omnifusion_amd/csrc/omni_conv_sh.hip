@@ -674,7 +674,9 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
     else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s);            // 8 waves
     else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
-    else if (rows <= 512 && ksteps >= 8 && !getenv("OMNI_CONV_NODEEP")) launch_sh<64, 64, 2, 2, 6>(a, s);   // a few blocks only (the transformer GEMMs): latency-bound, keep 5 stages in flight
+    // one round of at most one block per CU (the transformer GEMMs; every deep layer at batch 1): the K loop is pure latency,
+    // keep 5 stages in flight instead of 2 (96 KiB of LDS, which a single resident block can afford)
+    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !getenv("OMNI_CONV_NODEEP")) launch_sh<64, 64, 2, 2, 6>(a, s);
     else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
     if (a.splitk > 1) {

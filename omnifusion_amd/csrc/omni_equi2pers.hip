@@ -35,6 +35,7 @@ struct E2PArgs {
     float stepx, stepy;        // linspace(0,1,P) step (:29)
     float sx_scale, sy_scale;  // (W-1)/2, (H-1)/2  (grid_sample align_corners=True)
     int dbg;                   // tuning hook (OMNI_E2P_DBG): 1 = suppress stores, 2 = suppress box loads
+    const float2* ixy;         // per-geometry table of clamped sampling coordinates [N][ph][pw] (e2p_lds_kernel), or null
     PatchTab tab;
 };
 
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(256) void e2p_planar_kernel(E2PArgs a, int blocks_p
 // sample from LDS (ds_read2_b32).  The box of plane p+1 is in flight in registers while plane p is computed
 // (double-buffered LDS, one barrier per plane).  Tiles whose box does not fit (the pole itself lies inside, or
 // the ERP row pitch is not a multiple of 4) fall back to the direct gathers — wave-uniform branch, same taps.
-constexpr int E2P_TS = 32;                        // tile side (samples)
 constexpr int E2P_BOXF = 3968;                    // floats per LDS buffer: 2 buffers + 80 B < 32 KiB -> 5 blocks / CU
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -217,10 +217,32 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 
+// clamped sampling coordinates of patch sample (n, h, w): the closed-form geometry (two transcendentals per sample) followed
+// by grid_sample's align_corners=True scaling and border clamp (equi2pers_v3.py:95-104,111)
+__device__ __forceinline__ void e2p_sample_xy(const E2PArgs& a, int n, int h, int w, float& ix, float& iy)
+{
+    float lon, lat, x, q, tt, inv, u, v;
+    e2p_lonlat(a, n, h, w, lon, lat, x, q, tt, inv);
+    e2p_uv(lon, lat, u, v);
+    ix = (u + 1.0f) * a.sx_scale; iy = (v + 1.0f) * a.sy_scale;
+    ix = fminf((float)(a.W - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(a.H - 1), fmaxf(iy, 0.0f));
+}
+__global__ __launch_bounds__(256) void e2p_ixy_kernel(E2PArgs a, float2* __restrict__ tab, int total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int w = i % a.pw, h = (i / a.pw) % a.ph, n = i / (a.pw * a.ph);
+    float ix, iy;
+    e2p_sample_xy(a, n, h, w, ix, iy);
+    tab[i] = make_float2(ix, iy);
+}
+
 // Grid: blocks [0, ntiles) own one (patch, tile) each and run the LDS path; a tile that does not fit returns at once
 // and is covered by blocks [ntiles, ntiles + nfb*B): one block per (listed tile, batch item), direct gathers, so the
 // few pole tiles are spread over B times more blocks instead of serialising B*C planes in one straggler.
 // flags_out != nullptr: geometry-setup mode, only records which tiles need the gather path.
+template <int TS>                                 // tile side in samples: 32 (4 samples per thread) or 16 (1)
 __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, int tiles_per_patch, int ntiles,
                                                       const int* __restrict__ fb, unsigned char* flags_out)
 {
@@ -236,24 +258,26 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     else lb = omni_xcd_remap(blockIdx.x, ntiles);
     const int n = lb / tiles_per_patch;
     const int tile = lb % tiles_per_patch;
-    const int th0 = (tile / tiles_x) * E2P_TS, tw0 = (tile % tiles_x) * E2P_TS;
+    constexpr int SPT = TS * TS / 256, RSTEP = 256 / TS;        // samples per thread, row step between them
+    const int th0 = (tile / tiles_x) * TS, tw0 = (tile % tiles_x) * TS;
     const int t = threadIdx.x, wave = t >> 6;
-    const int col = t & 31, rowb = t >> 5;
+    const int col = t % TS, rowb = t / TS;
     const int W = a.W, H = a.H;
 
     // ---- taps of this thread's 4 samples (rows rowb + 8k of the tile, column col)
-    int x0[4], y0[4], y1[4], s1[4];
-    float w00[4], w01[4], w10[4], w11[4];
+    int x0[SPT], y0[SPT], y1[SPT], s1[SPT];
+    float w00[SPT], w01[SPT], w10[SPT], w11[SPT];
     const int w = min(tw0 + col, a.pw - 1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int h = min(th0 + rowb + 8 * k, a.ph - 1);
-        float lon, lat, x, q, tt, inv, u, v;
-        e2p_lonlat(a, n, h, w, lon, lat, x, q, tt, inv);
-        e2p_uv(lon, lat, u, v);
-        float ix = (u + 1.0f) * a.sx_scale, iy = (v + 1.0f) * a.sy_scale;
-        ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
-        iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    for (int k = 0; k < SPT; ++k) {
+        const int h = min(th0 + rowb + RSTEP * k, a.ph - 1);
+        float ix, iy;
+        if (a.ixy) {                                     // configuration constant: evaluated once per geometry handle by the
+            const float2 c = a.ixy[((size_t)n * a.ph + h) * a.pw + w];   // same device function (bit-identical), 8 bytes per sample
+            ix = c.x; iy = c.y;
+        } else {
+            e2p_sample_xy(a, n, h, w, ix, iy);
+        }
         const float fx = floorf(ix), fy = floorf(iy);
         x0[k] = (int)fx; y0[k] = (int)fy;
         const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
@@ -265,18 +289,19 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     if (t == 0) sh_xc = x0[0];
     __syncthreads();
     const int xc = sh_xc, half = W >> 1;
-    int dx[4];
+    int dx[SPT];
     int ymin = y0[0], ymax = y1[0];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         int d = x0[k] - xc;
         if (d >= half) d -= W;
         if (d < -half) d += W;
         dx[k] = d;
         ymin = min(ymin, y0[k]); ymax = max(ymax, y1[k]);
     }
-    int dmin = min(min(dx[0], dx[1]), min(dx[2], dx[3]));
-    int dmax = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
+    int dmin = dx[0], dmax = dx[0];
+#pragma unroll
+    for (int k = 1; k < SPT; ++k) { dmin = min(dmin, dx[k]); dmax = max(dmax, dx[k]); }
     ymin = wave_min(ymin); ymax = wave_max(ymax); dmin = wave_min(dmin); dmax = wave_max(dmax);
     if ((t & 63) == 0) { red[wave][0] = ymin; red[wave][1] = ymax; red[wave][2] = dmin; red[wave][3] = dmax; }
     __syncthreads();
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     const int bh = ymax - ymin + 1;
     const int bw4 = bw >> 2, nchunk = bh * bw4;
     const bool fits = ((W & 3) == 0) && (bw <= W) && (bh * bw <= E2P_BOXF);
-    const bool full = (th0 + E2P_TS <= a.ph) && (tw0 + E2P_TS <= a.pw);
+    const bool full = (th0 + TS <= a.ph) && (tw0 + TS <= a.pw);
 
     const float* erp = (const float*)a.erp;
     const int plane = a.ph * a.pw;
@@ -302,16 +327,17 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
     // this thread's 4 output elements: e0 + 8k rows
     float* out = (float*)a.pers + (size_t)n * a.C * plane + (size_t)(th0 + rowb) * a.pw + (tw0 + col);
-    const int ostep = 8 * a.pw;
+    const int ostep = RSTEP * a.pw;
 
     if (flags_out) { if (t == 0) flags_out[lb] = (fits && full) ? 0 : 1; return; }
     if (!fb_block && !(fits && full)) return;          // covered by the fallback blocks of this launch
     if ((a.dbg & 4) && fb_block) return;
     if ((a.dbg & 8) && !fb_block) return;
+    if (fb_block && blockIdx.y > 0) return;            // the fallback blocks walk every plane themselves
     if (!fb_block) {
-        int r0[4], r1[4];
+        int r0[SPT], r1[SPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SPT; ++k) {
             const int c0 = dx[k] - dmin + shift;
             r0[k] = (y0[k] - ymin) * bw + c0;
             r1[k] = (y1[k] - ymin) * bw + c0;
@@ -345,44 +371,50 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
             if (nj > 3 && tail_ok) __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[3]), (lptr_t)(buf + (wave * 64 + 768) * 4), 16, 0, 0);
         };
         float* const box0 = &box[0][0];
-        dma(erp, box0);
+        // blockIdx.y owns a contiguous range of the B*C image planes (small launches — few tiles, e.g. 18 patches of
+        // 128^2 — are split over the planes so that the chip is filled; the geometry prologue is repeated per range)
+        const int planes_all = a.B * a.C;
+        const int per = (planes_all + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int p_begin = (int)blockIdx.y * per, planes = min(planes_all, p_begin + per);
+        if (p_begin >= planes) return;
+        const float* img = erp + (size_t)p_begin * img_plane;
+        dma(img, box0 + (p_begin & 1) * E2P_BOXF);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* img = erp;
-        float* dst = out;
+        float* dst = out + (size_t)(p_begin / a.C) * out_bstride + (size_t)(p_begin % a.C) * plane;
         const size_t bskip = out_bstride - (size_t)a.C * plane;
-        int cc = 0;
-        const int planes = a.B * a.C;
-        for (int p = 0; p < planes; ++p) {
+        int cc = p_begin % a.C;
+        for (int p = p_begin; p < planes; ++p) {
             const float* cur = box0 + (p & 1) * E2P_BOXF;
             if (p + 1 < planes) { img += img_plane; dma(img, box0 + ((p + 1) & 1) * E2P_BOXF); }
-            float r[4];
+            float r[SPT];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SPT; ++k) {
                 const float a0 = cur[r0[k]], a1 = cur[r0[k] + 1];              // one ds_read2_b32 per tap row
                 const float b0 = cur[r1[k]], b1 = cur[r1[k] + 1];
                 r[k] = fmaf(s1[k] ? b1 : b0, w11[k], fmaf(b0, w10[k], fmaf(s1[k] ? a1 : a0, w01[k], a0 * w00[k])));
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k * ostep] = r[k];
+            for (int k = 0; k < SPT; ++k) dst[k * ostep] = r[k];
             dst += plane;
             if (++cc == a.C) { cc = 0; dst += bskip; }
             // counted wait: the DMA pieces are older than this trip's 4 stores, which may stay in flight across the
             // barrier (a plain __syncthreads() would drain them: its fence waits vmcnt(0) while an LDS-DMA is pending)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (SPT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else          asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
     } else {
         // direct gathers (same taps): tiles containing a pole, ragged tiles, odd row pitch
-        bool ok[4];
+        bool ok[SPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ok[k] = (th0 + rowb + 8 * k < a.ph) && (tw0 + col < a.pw);
+        for (int k = 0; k < SPT; ++k) ok[k] = (th0 + rowb + RSTEP * k < a.ph) && (tw0 + col < a.pw);
         float* dstb = out + (size_t)fb_b * out_bstride;
         for (int c = 0; c < a.C; ++c) {
             const float* img = erp + ((size_t)fb_b * a.C + c) * img_plane;
             float* dst = dstb + (size_t)c * plane;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SPT; ++k) {
                 const int g0 = y0[k] * W + x0[k], g1 = y1[k] * W + x0[k];
                 const float v00 = img[g0], v01 = img[g0 + s1[k]], v10 = img[g1], v11 = img[g1 + s1[k]];
                 const float r = fmaf(v11, w11[k], fmaf(v10, w10[k], fmaf(v01, w01[k], v00 * w00[k])));
@@ -487,6 +519,7 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
     a.stepy = g->ph > 1 ? 1.0f / (float)(g->ph - 1) : 0.0f;
     a.sx_scale = (float)(g->W - 1) / 2.0f; a.sy_scale = (float)(g->H - 1) / 2.0f;
     a.tab = g->e2p;
+    a.ixy = g->e2p_ixy;
     const char* d = getenv("OMNI_E2P_DBG"); a.dbg = d ? atoi(d) : 0;
 }
 
@@ -495,18 +528,40 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
 int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream)
 {
     E2PArgs a; fill_args(a, g, nullptr, nullptr, 1, 1);
-    const int tx = (g->pw + E2P_TS - 1) / E2P_TS, ty = (g->ph + E2P_TS - 1) / E2P_TS;
-    const int nt = g->N * tx * ty;
-    unsigned char* dflags = nullptr;
-    OMNI_HIP(hipMalloc((void**)&dflags, nt));
-    hipLaunchKernelGGL(e2p_lds_kernel, dim3(nt), dim3(256), 0, stream, a, tx, tx * ty, nt, (const int*)nullptr, dflags);
-    OMNI_HIP(hipGetLastError());
-    std::vector<unsigned char> hf(nt);
-    OMNI_HIP(hipMemcpyAsync(hf.data(), dflags, nt, hipMemcpyDeviceToHost, stream));
-    OMNI_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(dflags);
+    // sampling-coordinate table (8 bytes per patch sample: 9.4 MB at 18 x 256^2), read once per launch instead of two
+    // transcendentals per sample and tile
+    const long long total = (long long)g->N * g->ph * g->pw;
+    if (!g->e2p_ixy && total < (1ll << 28) && !getenv("OMNI_E2P_NOTAB")) {
+        OMNI_HIP(hipMalloc((void**)&g->e2p_ixy, sizeof(float2) * (size_t)total));
+        hipLaunchKernelGGL(e2p_ixy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, g->e2p_ixy, (int)total);
+        OMNI_HIP(hipGetLastError());
+        a.ixy = g->e2p_ixy;
+    }
+    // tiles whose ERP footprint does not fit the LDS box are listed once per geometry and take the gather fallback
     std::vector<int> list;
-    for (int i = 0; i < nt; ++i) if (hf[i]) list.push_back(i);
+    int ts = 32;
+    if (const char* te = getenv("OMNI_E2P_TS")) ts = atoi(te) == 16 ? 16 : 32;
+    for (;;) {
+        const int tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts;
+        const int nt = g->N * tx * ty;
+        unsigned char* dflags = nullptr;
+        OMNI_HIP(hipMalloc((void**)&dflags, nt));
+        if (ts == 32) hipLaunchKernelGGL(e2p_lds_kernel<32>, dim3(nt), dim3(256), 0, stream, a, tx, tx * ty, nt, (const int*)nullptr, dflags);
+        else          hipLaunchKernelGGL(e2p_lds_kernel<16>, dim3(nt), dim3(256), 0, stream, a, tx, tx * ty, nt, (const int*)nullptr, dflags);
+        OMNI_HIP(hipGetLastError());
+        std::vector<unsigned char> hf(nt);
+        OMNI_HIP(hipMemcpyAsync(hf.data(), dflags, nt, hipMemcpyDeviceToHost, stream));
+        OMNI_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(dflags);
+        list.clear();
+        for (int i = 0; i < nt; ++i) if (hf[i]) list.push_back(i);
+        if (getenv("OMNI_E2P_VERBOSE")) fprintf(stderr, "[omni] equi2pers %dx%d patches on %dx%d, %dx%d tiles: %d of %d take the gather fallback\n",
+                                                g->ph, g->pw, g->H, g->W, ts, ts, (int)list.size(), nt);
+        // (16x16 tiles — OMNI_E2P_TS=16 — cut the fallback count 3-5x where footprints are large (P = 128 at 512x1024, nrows = 6)
+        //  but amortise the per-tile prologue over a quarter of the samples: measured equal or slower, so not selected automatically)
+        break;
+    }
+    g->e2p_ts = ts;
     g->e2p_nfb = (int)list.size();
     if (!list.empty()) {
         OMNI_HIP(hipMalloc((void**)&g->e2p_fb_tiles, sizeof(int) * list.size()));
@@ -527,10 +582,15 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
         const char* var = getenv("OMNI_E2P_VAR");                                        // tuning hook
         if (var) sscanf(var, "%d,%d", &spt, &unr);
         if (sizeof(T) == 4 && !var && g->W >= 2) {
-            const int tx = (g->pw + E2P_TS - 1) / E2P_TS, ty = (g->ph + E2P_TS - 1) / E2P_TS;
+            const int ts = g->e2p_ts;
+            const int tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts;
             const int nt = N * tx * ty;
-            hipLaunchKernelGGL(e2p_lds_kernel, dim3(nt + g->e2p_nfb * B), dim3(256), 0, stream, a, tx, tx * ty, nt,
-                               (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
+            int psplit = 1;                                      // plane ranges (tuning hook; splitting repeats the per-tile prologue)
+            if (const char* pe = getenv("OMNI_E2P_PSPLIT")) psplit = atoi(pe) > 0 ? atoi(pe) : 1;
+            if (ts == 32) hipLaunchKernelGGL(e2p_lds_kernel<32>, dim3(nt + g->e2p_nfb * B, psplit), dim3(256), 0, stream, a, tx, tx * ty, nt,
+                                             (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
+            else          hipLaunchKernelGGL(e2p_lds_kernel<16>, dim3(nt + g->e2p_nfb * B, psplit), dim3(256), 0, stream, a, tx, tx * ty, nt,
+                                             (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
             OMNI_HIP(hipGetLastError());
             return OMNI_OK;
         }

@@ -111,7 +111,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     g->N = g->e2p.N;
     centers(nrows, 0, nullptr, nullptr, g->center_p);
     g->row_trig = nullptr; g->col_trig = nullptr; g->cand = nullptr; g->ntx = (W + 63) / 64;
-    g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0;
+    g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0; g->e2p_ixy = nullptr; g->e2p_ts = 32;
 
     if (H > 0 && W > 0) {
         const float PI_F = (float)M_PI, PI_2_F = (float)(M_PI * 0.5);
@@ -139,6 +139,7 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->col_trig) (void)hipFree(g->col_trig);
     if (g->cand) (void)hipFree(g->cand);
     if (g->e2p_fb_tiles) (void)hipFree(g->e2p_fb_tiles);
+    if (g->e2p_ixy) (void)hipFree(g->e2p_ixy);
     delete g;
 }
 

@@ -44,6 +44,8 @@ struct omni_geometry {
     int ntx;
     int* e2p_fb_tiles;             // equi2pers: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box
     int e2p_nfb;
+    int e2p_ts;                    // equi2pers: tile side (32 or 16 samples) chosen so that the footprints fit the LDS box
+    float2* e2p_ixy;               // equi2pers: clamped sampling coordinates (ix, iy) of every patch sample [N][ph][pw]
 };
 
 // implemented in omni_geometry.hip

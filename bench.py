@@ -199,9 +199,9 @@ def main():
                               "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
                               # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, profiles/r01f_resample_pmc.txt, B=8):
                               # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported
-                              "traffic": (2 * 51730 + 98300 + 2 * 21590 + 16380) * 1024 if B == 8 else None,
-                              "traffic_note": "equi2pers 105.9 MB read (2.1x its 50.3 MB input: footprint boxes of neighbouring "
-                                              "tiles overlap) + 100.7 MB written; pers2equi 44.2 MB read + 16.8 MB written",
+                              "traffic": (2 * 55030 + 98300 + 2 * 21540 + 16380) * 1024 if B == 8 else None,
+                              "traffic_note": "equi2pers 112.7 MB read (50.3 MB input, whose footprint boxes overlap between "
+                                              "neighbouring tiles, + the 9.4 MB sampling-coordinate table) + 100.7 MB written; pers2equi 44.1 MB read + 16.8 MB written",
                               "equi2pers": {"us": r_e2p * 1e6, "bytes": bytes_e2p, "GB/s": bytes_e2p / r_e2p / 1e9},
                               "pers2equi": {"us": r_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / r_p2e / 1e9}},
     }

@@ -117,6 +117,14 @@ int omni_pers2equi_g(const omni_geometry_t* g, const void* pers, void* erp, int 
  * ---------------------------------------------------------------------------------------------- */
 enum omni_act { OMNI_ACT_NONE = 0, OMNI_ACT_RELU = 1, OMNI_ACT_GELU = 2 };
 
+/* Backward of the two operators: the vector-Jacobian products that autograd derives from
+ * F.grid_sample (equi_pers/equi2pers_v3.py:111) and from the indexing gathers of equi_pers/pers2equi_v3.py:174-196 in the
+ * reference's training scripts (train_erp_depth.py:255-300).  Both operators are linear in the image.  fp32 only; the output
+ * gradient is overwritten; layouts as in the forward (grad_pers: OMNI_LAYOUT_BCHWN or _BNCHW). */
+int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dtype, int B, int C, int H, int W,
+                       int ph, int pw, int nrows, float fov_h, float fov_w, int layout, omni_stream_t stream);
+int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dtype, int B, int C, int ph, int pw,
+                       int H, int W, int nrows, float fov_h, float fov_w, int layout, omni_stream_t stream);
 /* dst[M,Ho,Wo,Cout] = act(conv(src1 ++ src2 (channel concat), wt) + bias + res) on the fp32 matrix cores
  * (v_mfma_f32_32x32x2_f32).  wt: [Cout][KH*KW*(C1+C2)], k ordered (ky,kx,c).  C1,C2,Cout multiples of 32.
  * Replaces: encoder BasicBlock convs model/spherical_model.py:122-167,257-261 (residual+ReLU fused), decoder

@@ -424,6 +424,43 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
     }
 }
 
+// ------------------------------------------------------------------ backward
+// g_erp[b,c,y,x] = sum over patch samples and their four taps of w_tap * g_pers[b,c,h,w,n]: the transpose of the bilinear
+// gather (ATen grid_sampler_2d_backward with bilinear / border / align_corners=True; taps outside the image are dropped).
+// One thread per patch sample, all B*C planes; fp32 hardware atomics into a zeroed g_erp (the summation order is not
+// deterministic, exactly like the reference's CUDA/HIP grid_sample backward).
+__global__ __launch_bounds__(256) void e2p_bwd_kernel(E2PArgs a /* erp = g_erp (out), pers = g_pers (in) */, int n_fastest, int total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int n, h, w;
+    if (n_fastest) { n = i % a.tab.N; w = (i / a.tab.N) % a.pw; h = i / (a.tab.N * a.pw); }     // [B,C,h,w,N]: coalesced reads
+    else           { w = i % a.pw; h = (i / a.pw) % a.ph; n = i / (a.pw * a.ph); }              // [B,N,C,h,w]
+    float ix, iy;
+    if (a.ixy) { const float2 c = a.ixy[((size_t)n * a.ph + h) * a.pw + w]; ix = c.x; iy = c.y; }
+    else e2p_sample_xy(a, n, h, w, ix, iy);
+    if (!(ix == ix) || !(iy == iy)) return;                       // q4: an odd x odd patch has a NaN centre sample
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
+    const bool okx = x0 + 1 < a.W, oky = y0 + 1 < a.H;
+    const size_t plane = (size_t)a.H * a.W, pp = (size_t)a.ph * a.pw;
+    float* gerp = (float*)a.erp;
+    const float* gp = (const float*)a.pers;
+    const size_t o00 = (size_t)y0 * a.W + x0;
+    for (int b = 0; b < a.B; ++b)
+        for (int c = 0; c < a.C; ++c) {
+            const size_t src = n_fastest ? ((((size_t)b * a.C + c) * a.ph + h) * a.pw + w) * a.tab.N + n
+                                         : (((size_t)b * a.tab.N + n) * a.C + c) * pp + (size_t)h * a.pw + w;
+            const float g = gp[src];
+            float* e = gerp + ((size_t)b * a.C + c) * plane + o00;
+            atomicAdd(e, g * (ey * ex));
+            if (okx) atomicAdd(e + 1, g * (ey * tx));
+            if (oky) atomicAdd(e + a.W, g * (ty * ex));
+            if (okx && oky) atomicAdd(e + a.W + 1, g * (ty * tx));
+        }
+}
+
 // ------------------------------------------------------------------ reference output [B,C,ph,pw,N]
 // A block owns one patch row h and TW = 64 columns for ALL N patches.  Wave v gathers patches
 // v, v+4, ... with lane <-> w (good ERP locality), parks the results in an LDS tile laid out
@@ -657,6 +694,30 @@ extern "C" int omni_equi2pers_aux(float* xyz, float* uv, int ph, int pw, int nro
     E2PArgs a; fill_args(a, g, nullptr, nullptr, 0, 0);
     const int total = g->N * ph * pw;
     hipLaunchKernelGGL(e2p_aux_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, xyz, uv);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// Vector-Jacobian product of equi2pers w.r.t. the ERP image (the operator is linear in it): grad_pers in the layout of the
+// forward's output, grad_erp [B,C,H,W] is overwritten.  fp32 only.  Replaces what autograd derives from F.grid_sample
+// (equi2pers_v3.py:111) in the reference's training scripts (train_erp_depth.py:255-300).
+extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dtype, int B, int C, int H, int W,
+                                  int ph, int pw, int nrows, float fov_h, float fov_w, int layout, omni_stream_t stream)
+{
+    if (dtype != OMNI_F32) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers_bwd: fp32 only");
+    if (layout != OMNI_LAYOUT_BCHWN && layout != OMNI_LAYOUT_BNCHW) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers_bwd: layout must be BCHWN or BNCHW");
+    const omni_geometry* g = nullptr;
+    int rc = omni_geometry_lookup(&g, nrows, fov_h, fov_w, ph, pw, H, W, (hipStream_t)stream);
+    if (rc != OMNI_OK) return rc;
+    if (B < 0 || C < 0) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers_bwd: negative batch/channels");
+    if (B == 0 || C == 0) return OMNI_OK;
+    if (!grad_pers || !grad_erp) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers_bwd: null device pointer");
+    E2PArgs a; fill_args(a, g, grad_erp, const_cast<void*>(grad_pers), B, C);
+    OMNI_HIP(hipMemsetAsync(grad_erp, 0, (size_t)B * C * H * W * sizeof(float), (hipStream_t)stream));
+    const long long total = (long long)g->N * ph * pw;
+    if (total >= (1ll << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers_bwd: too many patch samples");
+    hipLaunchKernelGGL(e2p_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       layout == OMNI_LAYOUT_BCHWN ? 1 : 0, (int)total);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

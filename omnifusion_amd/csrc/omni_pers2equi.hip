@@ -225,6 +225,55 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
     }
 }
 
+// ------------------------------------------------------------------ backward
+// g_pers[b,c,y,x,n] = sum over the ERP pixels (i,j) whose tap of patch n is (y,x) of w~ * g_erp[b,c,i,j], w~ the thresholded,
+// L1-normalised weights of the forward (the operator is linear in the patches; the weights do not depend on them).
+// One thread per ERP pixel, two passes over the candidate patches (normaliser, then scatter); fp32 hardware atomics into a
+// zeroed g_pers.
+__global__ __launch_bounds__(256) void p2e_bwd_kernel(P2EArgs a /* erp = g_erp (in), pers = g_pers (out) */, int nblocks)
+{
+    const unsigned lb = omni_xcd_remap(blockIdx.x, nblocks);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = lb % a.ntx;
+    const int i = __builtin_amdgcn_readfirstlane((int)(lb / a.ntx) * 4 + wave);
+    const int j = tx * 64 + lane;
+    if (i >= a.H) return;
+    const bool inside = j < a.W;
+    const float2 rt = a.row_trig[i];
+    const float2 ct = a.col_trig[inside ? j : a.W - 1];
+    const unsigned long long cm_ = a.cand[(size_t)i * a.ntx + tx];
+    const unsigned cm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ >> 32));
+    const unsigned cm_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ & 0xffffffffull));
+    const unsigned long long cmask = ((unsigned long long)cm_hi << 32) | (unsigned long long)cm_lo;
+    float l1 = 0.0f;
+    for (unsigned long long m = cmask; m;) {
+        const int n = __builtin_ctzll(m); m &= m - 1;
+        Taps t; p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+        l1 += (t.wa + t.wb) + (t.wc + t.wd);
+    }
+    if (!inside) return;
+    const float rden = 1.0f / fmaxf(l1, 1e-12f);
+    const float* gerp = (const float*)a.erp;
+    float* gp = (float*)const_cast<void*>(a.pers);
+    const size_t erp_plane = (size_t)a.H * a.W, pix = (size_t)i * a.W + j;
+    for (unsigned long long m = cmask; m;) {
+        const int n = __builtin_ctzll(m); m &= m - 1;
+        Taps t; p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+        if (!((t.wa + t.wb) + (t.wc + t.wd) > 0.0f)) continue;
+        const size_t oa = (size_t)n * a.sN + (size_t)t.y0 * a.sY + (size_t)t.x0 * a.sX, ob = (size_t)n * a.sN + (size_t)t.y1 * a.sY + (size_t)t.x0 * a.sX;
+        const size_t oc = (size_t)n * a.sN + (size_t)t.y0 * a.sY + (size_t)t.x1 * a.sX, od = (size_t)n * a.sN + (size_t)t.y1 * a.sY + (size_t)t.x1 * a.sX;
+        for (int b = 0; b < a.B; ++b)
+            for (int c = 0; c < a.C; ++c) {
+                const float g = gerp[((size_t)b * a.C + c) * erp_plane + pix] * rden;
+                float* q = gp + (size_t)b * a.sB + (size_t)c * a.sC;
+                if (t.wa != 0.0f) atomicAdd(q + oa, g * t.wa);
+                if (t.wb != 0.0f) atomicAdd(q + ob, g * t.wb);
+                if (t.wc != 0.0f) atomicAdd(q + oc, g * t.wc);
+                if (t.wd != 0.0f) atomicAdd(q + od, g * t.wd);
+            }
+    }
+}
+
 int fill_args(P2EArgs& a, const omni_geometry* g, const void* pers, const void* pers2, void* erp,
               int B, int C, int layout)
 {
@@ -330,4 +379,28 @@ extern "C" int omni_pers2equi_conf(const void* pred_w, const void* conf, float* 
     if (dtype == OMNI_F32) return launch_p2e<float, true>(g, pred_w, conf, out, B, 1, layout, (hipStream_t)stream);
     if (dtype == OMNI_F16) return launch_p2e<__half, true>(g, pred_w, conf, out, B, 1, layout, (hipStream_t)stream);
     OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi_conf: dtype must be OMNI_F32 or OMNI_F16");
+}
+
+// Vector-Jacobian product of pers2equi w.r.t. the patches: grad_erp [B,C,H,W] -> grad_pers in the layout of the forward's
+// input (overwritten).  fp32 only.  Replaces what autograd derives from the advanced-indexing gathers of
+// pers2equi_v3.py:174-196 in the reference's training scripts.
+extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dtype, int B, int C, int ph, int pw,
+                                  int H, int W, int nrows, float fov_h, float fov_w, int layout, omni_stream_t stream)
+{
+    if (dtype != OMNI_F32) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_pers2equi_bwd: fp32 only");
+    const omni_geometry* g = nullptr;
+    int rc = omni_geometry_lookup(&g, nrows, fov_h, fov_w, ph, pw, H, W, (hipStream_t)stream);
+    if (rc != OMNI_OK) return rc;
+    rc = check_common(g, B, C, "omni_pers2equi_bwd");
+    if (rc != OMNI_OK) return rc;
+    if (B == 0 || C == 0) return OMNI_OK;
+    if (!grad_erp || !grad_pers) OMNI_FAIL(OMNI_ERR_INVALID, "omni_pers2equi_bwd: null device pointer");
+    P2EArgs a;
+    rc = fill_args(a, g, grad_pers, nullptr, const_cast<void*>(grad_erp), B, C, layout);
+    if (rc != OMNI_OK) return rc;
+    OMNI_HIP(hipMemsetAsync(grad_pers, 0, (size_t)B * C * g->N * ph * pw * sizeof(float), (hipStream_t)stream));
+    const int rows4 = (g->H + 3) / 4, nblocks = rows4 * g->ntx;
+    hipLaunchKernelGGL(p2e_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a, nblocks);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
 }

@@ -12,7 +12,8 @@ Same name, arguments, return tuple, layouts and dtypes as the reference:
               erp_img.device and center_p[N,2] on the CPU      (reference :82,118,122)
 
 All arithmetic runs in libomnifusion_hip.so (csrc/omni_equi2pers.hip) on the caller's
-current stream.  Inference only: tensors that require grad are rejected.
+current stream.  Like the reference's (which autograd differentiates through F.grid_sample, :111), `pers` is
+differentiable w.r.t. `erp_img` (float32): the backward is the HIP scatter kernel `omni_equi2pers_bwd`.
 Errors: ValueError for bad nrows/shape/dtype/device (the reference raises
 UnboundLocalError for an unsupported nrows), RuntimeError for HIP failures.
 """
@@ -37,15 +38,40 @@ def _check_input(t, name, ndim):
     if not t.is_cuda:
         raise ValueError(f"{name} must live on an MI355X device (got {t.device}); "
                          "this package has no CPU path")
-    if t.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError(f"{name} requires grad: the HIP path is inference-only "
-                           "(wrap the call in torch.no_grad())")
+    if t.requires_grad and torch.is_grad_enabled() and t.dtype != torch.float32:
+        raise RuntimeError(f"{name} requires grad: the HIP backward is float32 only")
+
+
+class _Equi2PersFn(torch.autograd.Function):
+    """pers = equi2pers(erp) with the HIP backward (the operator is linear in erp: grad_erp = J^T grad_pers)."""
+
+    @staticmethod
+    def forward(ctx, erp_img, fov, nrows, patch_size, layout):
+        ctx.cfg = (fov, nrows, patch_size, layout, tuple(erp_img.shape))
+        with torch.no_grad():
+            return equi2pers_patches(erp_img.detach(), fov, nrows, patch_size, layout)
+
+    @staticmethod
+    def backward(ctx, grad_pers):
+        fov, nrows, patch_size, layout, (B, C, H, W) = ctx.cfg
+        lib = _lib.load()
+        ph, pw = (int(v) for v in pair(patch_size))
+        fov_h, fov_w = (float(v) for v in pair(fov))
+        g = grad_pers.contiguous().float()
+        grad_erp = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.omni_equi2pers_bwd(_lib.ptr(g), _lib.ptr(grad_erp), _lib.F32, B, C, H, W, ph, pw, int(nrows),
+                                        ctypes.c_float(fov_h), ctypes.c_float(fov_w), int(layout), _lib.stream_of(g))
+        _lib.check(rc, "equi2pers backward")
+        return grad_erp, None, None, None, None
 
 
 def equi2pers_patches(erp_img, fov, nrows, patch_size, layout=_lib.LAYOUT_BCHWN):
     """Only the sampled patches, in the reference layout [B,C,h,w,N] (default) or in the
     patch-major planar layout [B,N,C,h,w] the model uses internally."""
     _check_input(erp_img, "erp_img", 4)
+    if erp_img.requires_grad and torch.is_grad_enabled():
+        return _Equi2PersFn.apply(erp_img, fov, nrows, patch_size, layout)
     lib = _lib.load()
     if nrows not in _NPATCH:
         raise ValueError(f"unsupported nrows={nrows!r}: presets are 3, 4, 5, 6")

@@ -8,7 +8,8 @@
                ./grid/<layer_name>.pth table cache (:24-29); nothing is written to disk here.
     returns    Tensor[B,C,H,W] on pers_img.device
 
-All arithmetic runs in libomnifusion_hip.so (csrc/omni_pers2equi.hip).
+All arithmetic runs in libomnifusion_hip.so (csrc/omni_pers2equi.hip).  Differentiable w.r.t. `pers_img` (float32) like
+the reference's indexing gathers (:174-196): the backward is the HIP scatter kernel `omni_pers2equi_bwd`.
 """
 import ctypes
 
@@ -42,8 +43,34 @@ def _patch_dims(t, layout, ph, pw, nrows):
     return B, C
 
 
+class _Pers2EquiFn(torch.autograd.Function):
+    """erp = pers2equi(pers) with the HIP backward (linear in pers: grad_pers = J^T grad_erp)."""
+
+    @staticmethod
+    def forward(ctx, pers_img, fov, nrows, patch_size, erp_size, layout):
+        ctx.cfg = (fov, nrows, patch_size, erp_size, layout, tuple(pers_img.shape))
+        with torch.no_grad():
+            return pers2equi(pers_img.detach(), fov, nrows, patch_size, erp_size, None, layout)
+
+    @staticmethod
+    def backward(ctx, grad_erp):
+        fov, nrows, patch_size, erp_size, layout, shape = ctx.cfg
+        lib = _lib.load()
+        ph, pw, fov_h, fov_w, H, W = _args(fov, patch_size, erp_size)
+        g = grad_erp.contiguous().float()
+        B, C = g.shape[0], g.shape[1]
+        grad_pers = torch.empty(shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.omni_pers2equi_bwd(_lib.ptr(g), _lib.ptr(grad_pers), _lib.F32, B, C, ph, pw, H, W, int(nrows),
+                                        ctypes.c_float(fov_h), ctypes.c_float(fov_w), int(layout), _lib.stream_of(g))
+        _lib.check(rc, "pers2equi backward")
+        return grad_pers, None, None, None, None, None
+
+
 def pers2equi(pers_img, fov, nrows, patch_size, erp_size, layer_name=None, layout=_lib.LAYOUT_BCHWN):
     _check_input(pers_img, "pers_img", 5)
+    if pers_img.requires_grad and torch.is_grad_enabled():
+        return _Pers2EquiFn.apply(pers_img, fov, nrows, patch_size, erp_size, layout)
     lib = _lib.load()
     ph, pw, fov_h, fov_w, H, W = _args(fov, patch_size, erp_size)
     B, C = _patch_dims(pers_img, layout, ph, pw, nrows)

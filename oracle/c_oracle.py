@@ -35,6 +35,8 @@ def lib():
         _lib.omni_oracle_pers2equi.restype = ctypes.c_int
         _lib.omni_oracle_pers2equi_tables.restype = ctypes.c_int
         _lib.omni_oracle_pers2equi_conf.restype = ctypes.c_int
+        _lib.omni_oracle_equi2pers_bwd.restype = ctypes.c_int
+        _lib.omni_oracle_pers2equi_bwd.restype = ctypes.c_int
     return _lib
 
 
@@ -116,4 +118,31 @@ def pers2equi_conf(pred_w, conf, fov, nrows, patch_size, erp_size):
                                          ctypes.c_float(fh), ctypes.c_float(fw), H, W, _fp(out))
     if r < 0:
         raise RuntimeError("omni_oracle_pers2equi_conf failed")
+    return out
+
+
+def equi2pers_bwd(grad_pers, fov, nrows, erp_size):
+    """vector-Jacobian product of equi2pers w.r.t. the ERP image: grad_pers [B,C,h,w,N] -> grad_erp [B,C,H,W]"""
+    g = np.ascontiguousarray(grad_pers, np.float32)
+    B, C, ph, pw, N = g.shape
+    fh, fw = _pair(fov)
+    H, W = _pair(erp_size)
+    out = np.empty((B, C, H, W), np.float32)
+    r = lib().omni_oracle_equi2pers_bwd(_fp(g), B, C, H, W, ctypes.c_float(fh), ctypes.c_float(fw), int(nrows), ph, pw, _fp(out))
+    if r != N:
+        raise RuntimeError(f"omni_oracle_equi2pers_bwd failed: {r}")
+    return out
+
+
+def pers2equi_bwd(grad_erp, fov, nrows, patch_size):
+    """vector-Jacobian product of pers2equi w.r.t. the patches: grad_erp [B,C,H,W] -> grad_pers [B,C,h,w,N]"""
+    g = np.ascontiguousarray(grad_erp, np.float32)
+    B, C, H, W = g.shape
+    ph, pw = _pair(patch_size)
+    fh, fw = _pair(fov)
+    N = patch_centers(nrows, 1)[0].shape[0]
+    out = np.empty((B, C, ph, pw, N), np.float32)
+    r = lib().omni_oracle_pers2equi_bwd(_fp(g), B, C, ph, pw, int(nrows), ctypes.c_float(fh), ctypes.c_float(fw), H, W, _fp(out))
+    if r != N:
+        raise RuntimeError(f"omni_oracle_pers2equi_bwd failed: {r}")
     return out

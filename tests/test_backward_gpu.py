@@ -1,0 +1,87 @@
+"""GPU: the HIP backward of equi2pers / pers2equi (omni_equi2pers_bwd, omni_pers2equi_bwd, reached through autograd on the
+drop-in functions) against (i) gradients of the REFERENCE functions (goldens G10/G11), (ii) the C oracle on other sizes and
+layouts, (iii) the adjoint identity <J x, y> = <x, J^T y> at BASELINE cfg 1 size.  fp32 atomics: the summation order is not
+deterministic, tolerances as in tests/test_backward_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from _util import golden, rng_uniform, assert_close_outliers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers, equi2pers_patches
+    from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi
+    from omnifusion_amd import _lib
+    return equi2pers, equi2pers_patches, pers2equi, _lib
+
+
+@pytest.mark.parametrize("name", ["G10_e2p_bwd", "G10b_e2p_bwd_n6"])
+def test_equi2pers_backward_golden(name):
+    equi2pers, _, _, _ = _ops()
+    g = golden(name)
+    H, W, nrows, P, B, C = (int(v) for v in g["meta"])
+    erp = torch.rand((B, C, H, W), device=DEV, requires_grad=True)
+    pers = equi2pers(erp, (80, 80), nrows, (P, P))[0]
+    assert pers.requires_grad
+    (pers * torch.from_numpy(g["grad_pers"]).to(DEV)).sum().backward()
+    assert_close_outliers(erp.grad.cpu().numpy(), g["grad_erp"], tol=2e-4, max_tol=2e-3, frac=1e-4, what=name)
+
+
+@pytest.mark.parametrize("name", ["G11_p2e_bwd", "G11b_p2e_bwd_n6"])
+def test_pers2equi_backward_golden(name):
+    _, _, pers2equi, _ = _ops()
+    g = golden(name)
+    H, W, nrows, P, B, C = (int(v) for v in g["meta"])
+    N = g["grad_pers"].shape[-1]
+    pers = torch.rand((B, C, P, P, N), device=DEV, requires_grad=True)
+    erp = pers2equi(pers, (80, 80), nrows, (P, P), (H, W), "bwd")
+    (erp * torch.from_numpy(g["grad_erp"]).to(DEV)).sum().backward()
+    assert_close_outliers(pers.grad.cpu().numpy(), g["grad_pers"], tol=2e-4, max_tol=2e-3, frac=1e-4, what=name)
+
+
+def test_backward_vs_oracle_planar_layout_and_rect():
+    """other sizes (rectangular patches, nrows 3 and 5) and the planar [B,N,C,h,w] layout the model uses"""
+    _, equi2pers_patches, pers2equi, L = _ops()
+    for nrows, (ph, pw), (H, W) in ((3, (9, 14), (40, 96)), (5, (16, 16), (64, 128))):
+        N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+        gy = rng_uniform(21, (2, 2, ph, pw, N))
+        want = co.equi2pers_bwd(gy, (80, 80), nrows, (H, W))
+        for layout in (L.LAYOUT_BCHWN, L.LAYOUT_BNCHW):
+            erp = torch.rand((2, 2, H, W), device=DEV, requires_grad=True)
+            out = equi2pers_patches(erp, (80, 80), nrows, (ph, pw), layout=layout)
+            gyt = torch.from_numpy(gy).to(DEV)
+            if layout == L.LAYOUT_BNCHW:
+                gyt = gyt.permute(0, 4, 1, 2, 3).contiguous()
+            (out * gyt).sum().backward()
+            assert_close_outliers(erp.grad.cpu().numpy(), want, tol=2e-4, max_tol=2e-3, frac=1e-4, what=f"e2p bwd {nrows} {layout}")
+        ge = rng_uniform(22, (2, 2, H, W))
+        want = co.pers2equi_bwd(ge, (80, 80), nrows, (ph, pw))
+        for layout in (L.LAYOUT_BCHWN, L.LAYOUT_BNCHW):
+            shape = (2, 2, ph, pw, N) if layout == L.LAYOUT_BCHWN else (2, N, 2, ph, pw)
+            pers = torch.rand(shape, device=DEV, requires_grad=True)
+            e = pers2equi(pers, (80, 80), nrows, (ph, pw), (H, W), None, layout=layout)
+            (e * torch.from_numpy(ge).to(DEV)).sum().backward()
+            got = pers.grad if layout == L.LAYOUT_BCHWN else pers.grad.permute(0, 2, 3, 4, 1)
+            assert_close_outliers(got.cpu().numpy(), want, tol=2e-4, max_tol=2e-3, frac=1e-4, what=f"p2e bwd {nrows} {layout}")
+
+
+def test_adjoint_identity_config1_size():
+    """<J x, y> == <x, J^T y> for both operators at 512x1024 / 18 x 256^2 (size-independent property of a linear map)"""
+    equi2pers, _, pers2equi, _ = _ops()
+    x = torch.rand((1, 3, 512, 1024), device=DEV, requires_grad=True)
+    fwd = equi2pers(x, (80, 80), 4, (256, 256))[0]
+    y = torch.rand_like(fwd)
+    (fwd * y).sum().backward()
+    lhs = float((fwd.detach().double() * y.double()).sum()); rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * abs(lhs)
+    p = torch.rand((1, 1, 256, 256, 18), device=DEV, requires_grad=True)
+    e = pers2equi(p, (80, 80), 4, (256, 256), (512, 1024), "adj")
+    z = torch.rand_like(e)
+    (e * z).sum().backward()
+    lhs = float((e.detach().double() * z.double()).sum()); rhs = float((p.detach().double() * p.grad.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * abs(lhs)

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void e2p_ixy_kernel(E2PArgs a, float2* __restr
 // and is covered by blocks [ntiles, ntiles + nfb*B): one block per (listed tile, batch item), direct gathers, so the
 // few pole tiles are spread over B times more blocks instead of serialising B*C planes in one straggler.
 // flags_out != nullptr: geometry-setup mode, only records which tiles need the gather path.
-template <int TS>                                 // tile side in samples: 32 (4 samples per thread) or 16 (1)
+// BWD: the transposed operator — a.pers holds g_pers (read), a.erp g_erp (zeroed by the host, accumulated here): every tile
+// accumulates its footprint box in LDS (ds_add_f32) and flushes it with coalesced global atomics, 16 bytes per lane
+template <int TS, bool BWD = false>               // tile side in samples: 32 (4 samples per thread) or 16 (1)
 __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, int tiles_per_patch, int ntiles,
                                                       const int* __restrict__ fb, unsigned char* flags_out)
 {
@@ -371,6 +373,48 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
             if (nj > 3 && tail_ok) __builtin_amdgcn_global_load_lds((gptr_t)(img + goff[3]), (lptr_t)(buf + (wave * 64 + 768) * 4), 16, 0, 0);
         };
         float* const box0 = &box[0][0];
+        if (BWD) {
+            // ---- transposed trip per plane: zero my chunks | barrier | 4 x 4 ds_add_f32 | barrier | flush my chunks (global atomics)
+            float* gerp = (float*)a.erp;
+            const float* src = (const float*)a.pers + (size_t)n * a.C * plane + (size_t)(th0 + rowb) * a.pw + (tw0 + col);
+            const size_t bskip = out_bstride - (size_t)a.C * plane;
+            int cc = 0;
+            const int planes = a.B * a.C;
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < planes; ++p) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qc = wave * 64 + 256 * j + lane;
+                    if (j < nj && qc < nchunk) *reinterpret_cast<float4*>(box0 + qc * 4) = zero4;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) {
+                    const float g = src[k * ostep];
+                    atomicAdd(box0 + r0[k], g * w00[k]);
+                    atomicAdd(box0 + r0[k] + s1[k], g * w01[k]);          // s1 == 0: the +1 column is outside and its weight exactly 0
+                    atomicAdd(box0 + r1[k], g * w10[k]);
+                    atomicAdd(box0 + r1[k] + s1[k], g * w11[k]);
+                }
+                __syncthreads();
+                float* ge = gerp + (size_t)p * img_plane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qc = wave * 64 + 256 * j + lane;
+                    if (j < nj && qc < nchunk) {
+                        const float4 v = *reinterpret_cast<const float4*>(box0 + qc * 4);
+                        float* q = ge + goff[j];
+                        if (v.x != 0.0f) atomicAdd(q, v.x);
+                        if (v.y != 0.0f) atomicAdd(q + 1, v.y);
+                        if (v.z != 0.0f) atomicAdd(q + 2, v.z);
+                        if (v.w != 0.0f) atomicAdd(q + 3, v.w);
+                    }
+                }
+                src += plane;
+                if (++cc == a.C) { cc = 0; src += bskip; }
+            }
+            return;
+        }
         // blockIdx.y owns a contiguous range of the B*C image planes (small launches — few tiles, e.g. 18 patches of
         // 128^2 — are split over the planes so that the chip is filled; the geometry prologue is repeated per range)
         const int planes_all = a.B * a.C;
@@ -409,6 +453,23 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
         bool ok[SPT];
 #pragma unroll
         for (int k = 0; k < SPT; ++k) ok[k] = (th0 + rowb + RSTEP * k < a.ph) && (tw0 + col < a.pw);
+        if (BWD) {                                                // direct global atomics for this (tile, batch item)
+            float* gerp = (float*)a.erp;
+            const float* srcb = (const float*)a.pers + (size_t)n * a.C * plane + (size_t)(th0 + rowb) * a.pw + (tw0 + col)
+                              + (size_t)fb_b * out_bstride;
+            for (int c = 0; c < a.C; ++c) {
+                float* ge = gerp + ((size_t)fb_b * a.C + c) * img_plane;
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) {
+                    if (!ok[k] || !(w00[k] == w00[k])) continue;              // outside a ragged tile / NaN sample (q4)
+                    const float g = srcb[(size_t)c * plane + k * ostep];
+                    const int g0 = y0[k] * W + x0[k], g1 = y1[k] * W + x0[k];
+                    atomicAdd(ge + g0, g * w00[k]); atomicAdd(ge + g0 + s1[k], g * w01[k]);
+                    atomicAdd(ge + g1, g * w10[k]); atomicAdd(ge + g1 + s1[k], g * w11[k]);
+                }
+            }
+            return;
+        }
         float* dstb = out + (size_t)fb_b * out_bstride;
         for (int c = 0; c < a.C; ++c) {
             const float* img = erp + ((size_t)fb_b * a.C + c) * img_plane;
@@ -716,6 +777,16 @@ extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dty
     OMNI_HIP(hipMemsetAsync(grad_erp, 0, (size_t)B * C * H * W * sizeof(float), (hipStream_t)stream));
     const long long total = (long long)g->N * ph * pw;
     if (total >= (1ll << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers_bwd: too many patch samples");
+    if (layout == OMNI_LAYOUT_BNCHW && g->W >= 2 && !getenv("OMNI_E2P_BWD_SIMPLE")) {
+        // planar layout: the transposed LDS-box kernel (same tiling and fallback list as the forward)
+        const int ts = g->e2p_ts, tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts, nt = g->N * tx * ty;
+        if (ts == 32) hipLaunchKernelGGL((e2p_lds_kernel<32, true>), dim3(nt + g->e2p_nfb * B), dim3(256), 0, (hipStream_t)stream, a, tx, tx * ty, nt,
+                                         (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
+        else          hipLaunchKernelGGL((e2p_lds_kernel<16, true>), dim3(nt + g->e2p_nfb * B), dim3(256), 0, (hipStream_t)stream, a, tx, tx * ty, nt,
+                                         (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
+    }
     hipLaunchKernelGGL(e2p_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
                        layout == OMNI_LAYOUT_BCHWN ? 1 : 0, (int)total);
     OMNI_HIP(hipGetLastError());

@@ -142,7 +142,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: LDS-DMA bases stay in scalar registers
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = a.Cout / BN;
-    const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x % ntn;
+    // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous range of (tile_m, tile_n) so that the
+    // blocks sharing an A row tile (and neighbouring pixels) share one L2
+    const unsigned lb = a.dbg & 8 ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lb / ntn, tile_n = lb % ntn;
     const int row0 = tile_m * BM, col0 = tile_n * BN;
     const int G1 = a.C1 >> 5, G2 = a.C2 >> 5, G = G1 + G2;
     const int ksteps = a.KH * a.KW * G;

@@ -79,11 +79,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    # one rank per GPU.  (OMNI_BENCH_DIST_BACKEND=gloo lets the rank/timing logic be exercised with several ranks sharing one
+    # GPU on a single-GPU box; the real launch is nccl = RCCL with LOCAL_RANK == device index.)
+    backend = os.environ.get("OMNI_BENCH_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
@@ -129,7 +136,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert depth.shape == (B, 1, ERP_H, ERP_W) and bool(torch.isfinite(depth).all())

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / TH;
-    int bid = blockIdx.x;
+    int bid = a.dbg & 8 ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halos, same A for all tile_n) on one XCD
     const int tile_n = bid % ntn; bid /= ntn;
     const int tx = bid % tw; bid /= tw;
     const int ty = bid % th; const int m = bid / th;

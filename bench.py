@@ -74,25 +74,36 @@ def cpu_baseline():
                       f"({threads} threads) + C/OpenMP equi2pers/pers2equi"}
 
 
+def pmc_traffic(B):
+    """HBM bytes of the resample pair (one launch each) from profiles/resample_traffic.json, or (None, why)."""
+    path = os.path.join(ROOT, "profiles", "resample_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/resample_traffic.json not present"
+    with open(path) as fh:
+        d = json.load(fh)
+    from omnifusion_amd.build import source_hash
+    if d.get("build") != source_hash():
+        return None, f"profiles/resample_traffic.json was measured on build {d.get('build')}, this is {source_hash()}"
+    if d.get("B") != B:
+        return None, f"profiles/resample_traffic.json was measured at B={d.get('B')}"
+    return d["traffic_bytes"], d.get("note", "")
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from omnifusion_amd import dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain process: become N ranks, one per GPU (the driver's own launch form:
+        # python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+        sys.exit(dist.respawn_under_launcher(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
-    # one rank per GPU.  (OMNI_BENCH_DIST_BACKEND=gloo lets the rank/timing logic be exercised with several ranks sharing one
-    # GPU on a single-GPU box; the real launch is nccl = RCCL with LOCAL_RANK == device index.)
+    # one rank per GPU over RCCL.  (OMNI_BENCH_DIST_BACKEND=gloo lets the multi-rank path be exercised with several ranks
+    # sharing one GPU on a single-GPU box; the real launch is nccl = RCCL with LOCAL_RANK == device index.)
     backend = os.environ.get("OMNI_BENCH_DIST_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(backend)
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
+    rank, local, world, dev = dist.init(backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    local = dev.index
 
     from omnifusion_amd import _lib
     from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
@@ -109,36 +120,29 @@ def main():
     eng = net._eng
     LAY = _lib.LAYOUT_BNCHW
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
     # Bring the GPU out of its idle power state before anything is counted (sclk idles at ~366 MHz and takes tens of
     # milliseconds of load to ramp: a 5-step warm-up measured 1600-2200 panoramas/s on a box that then holds 2650).
     t_heat = time.perf_counter()
     while time.perf_counter() - t_heat < 0.3:
         net(rgb, confidence=True)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        net(rgb, confidence=True)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):                                               # = spherical_fusion.forward, stage by stage
-        ev[k][0].record()
+    state = {"k": -args.warmup, "depth": None}
+
+    def step():                                                               # = spherical_fusion.forward, stage by stage
+        k = state["k"]; state["k"] = k + 1
+        e = ev[k] if k >= 0 else None                                         # warm-up steps carry no events
+        if e: e[0].record()
         patches = equi2pers_patches(rgb, FOV, NROWS, (128, 128), layout=LAY)
-        ev[k][1].record()
+        if e: e[1].record()
         a, c = net.network(patches, B, True)
-        ev[k][2].record()
-        depth = eng.blend(a, c, (ERP_H, ERP_W))
-        ev[k][3].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        if e: e[2].record()
+        state["depth"] = eng.blend(a, c, (ERP_H, ERP_W))
+        if e: e[3].record()
+
+    # W untimed steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize, MAX over ranks (omnifusion_amd/dist.py)
+    dt = dist.timed_steps(step, args.steps, args.warmup, dev)
+    depth = state["depth"]
     assert depth.shape == (B, 1, ERP_H, ERP_W) and bool(torch.isfinite(depth).all())
     sec = lambda i: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) * 1e-3
     t_e2p, t_net, t_p2e = sec(0), sec(1), sec(2)
@@ -166,6 +170,8 @@ def main():
     bytes_e2p = B * 3 * (ERP_H * ERP_W + P * P * NPATCH) * 4          # SURVEY 8d algorithmic bytes
     bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * 4
     gbs_pair = (bytes_e2p + bytes_p2e) / (r_e2p + r_p2e) / 1e9
+
+    traffic, traffic_note = pmc_traffic(B)
 
     # ---- BASELINE cfg 2 as written (ONE panorama per forward): latency-bound, reported next to the batched figure
     one = rgb[:1].contiguous()
@@ -204,19 +210,17 @@ def main():
                              "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         "roofline_resample": {"bound": "hbm", "kernel": "e2p_lds_kernel + p2e_kernel<float,8,false,true> at 18x256^2, B=%d" % B,
                               "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
-                              # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, profiles/r01f_resample_pmc.txt, B=8):
-                              # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported
-                              "traffic": (2 * 55030 + 98300 + 2 * 21540 + 16380) * 1024 if B == 8 else None,
-                              "traffic_note": "equi2pers 112.7 MB read (50.3 MB input, whose footprint boxes overlap between "
-                                              "neighbouring tiles, + the 9.4 MB sampling-coordinate table) + 100.7 MB written; pers2equi 44.1 MB read + 16.8 MB written",
+                              # HBM bytes per launch pair from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE doubled as
+                              # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), written by tools/pmc_traffic.sh
+                              # together with the hash of the sources it was measured on: null when that is not THIS build
+                              "traffic": traffic, "traffic_note": traffic_note,
                               "equi2pers": {"us": r_e2p * 1e6, "bytes": bytes_e2p, "GB/s": bytes_e2p / r_e2p / 1e9},
                               "pers2equi": {"us": r_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / r_p2e / 1e9}},
     }
     if rank == 0:
         out["cpu_baseline"] = None if args.no_cpu_baseline or world > 1 else cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    dist.finalize()
 
 
 if __name__ == "__main__":

@@ -26,6 +26,20 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash():
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.h, include/*.h): ties a measurement file under
+    profiles/ to the build it was taken on (bench.py reports PMC traffic only when the hashes agree)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
+        sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

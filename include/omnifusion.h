@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OMNI_VERSION 100
+#define OMNI_VERSION 200
 
 enum omni_status {
     OMNI_OK = 0,
@@ -44,6 +44,13 @@ typedef struct omni_geometry omni_geometry_t;
 
 int omni_version(void);
 const char* omni_last_error(void);
+
+/* Tuning options (tile shapes, kernel selection, cache size — csrc/omni_internal.h `OmniOptions`; each also has an
+ * OMNI_<NAME> environment variable that is read ONCE, when the library first needs it).  No option changes a result
+ * bit except "splitk_max" (K summation order).  Unknown name -> OMNI_ERR_INVALID.  No reference counterpart (the
+ * reference has no tunables below PyTorch); used by tests/ and tools/ to sweep kernel variants. */
+int omni_set_option(const char* name, int value);
+int omni_get_option(const char* name, int* value);
 
 /* Number of patches for an nrows preset (3,4,5,6 -> 10,18,26,46), -1 otherwise.
  * equi2pers_v3.py:32-47 / pers2equi_v3.py:36-51 (the reference raises
@@ -66,7 +73,10 @@ int omni_patch_centers(int nrows, int which, float* center_p_host);
 int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_h, float fov_w,
                          int ph, int pw, int H, int W, omni_stream_t stream);
 void omni_geometry_destroy(omni_geometry_t* g);
+/* The internal cache is an LRU capped at option "geom_cache_max" (default 16) handles; evicted / cleared handles are
+ * destroyed only after their device has drained.  omni_geometry_cache_size: handles currently cached (all devices). */
 void omni_geometry_cache_clear(void);
+int omni_geometry_cache_size(void);
 
 /*
  * equi2pers — replaces equi_pers/equi2pers_v3.py:20 `equi2pers(erp_img, fov, nrows, patch_size)`
@@ -162,6 +172,11 @@ int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16
                             omni_stream_t stream);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
+/* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a
+ * sticky per-device flag records it.  *flag = 1 if that happened on the current device since the flag was last cleared
+ * (reset != 0 clears it).  Synchronises the device: diagnostic only.  The fp32 reference has no such limit
+ * (model/spherical_model.py runs fp32 end to end): a checkpoint that trips the flag needs OMNI_NET_PRECISION=fp32. */
+int omni_sh_overflow(int* flag, int reset);
 /* conv1 7x7 s2 p3 (3->64) + bn1 + ReLU, model/spherical_model.py:254.  src planar [M,3,P,P]
  * (OMNI_LAYOUT_BNCHW patches), wt [147][64] (k = (ky*7+kx)*3+c), dst NHWC [M,P/2,P/2,64]. */
 int omni_stem_f32(const float* src, const float* wt, const float* bias, float* dst, int M, int P, omni_stream_t stream);

@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libomnifusion_hip.so")
+LIB_PATH_DEBUG = os.path.join(_HERE, "csrc", "libomnifusion_hip_dbg.so")     # tools/ only: ablation switches + micro-benchmarks
 
 OMNI_OK, OMNI_ERR_INVALID, OMNI_ERR_HIP, OMNI_ERR_UNSUPPORTED = 0, 1, 2, 3
 LAYOUT_BCHWN, LAYOUT_BNCHW, LAYOUT_BNHWC = 0, 1, 2
@@ -24,14 +25,14 @@ class OmniLibraryMissing(ImportError):
 # every symbol include/omnifusion.h declares (tests/test_boundary.py parses the header and
 # checks this list against it and against the built library)
 EXPORTS = [
-    "omni_version", "omni_last_error", "omni_num_patches", "omni_patch_centers",
-    "omni_geometry_create", "omni_geometry_destroy", "omni_geometry_cache_clear",
+    "omni_version", "omni_last_error", "omni_set_option", "omni_get_option", "omni_num_patches", "omni_patch_centers",
+    "omni_geometry_create", "omni_geometry_destroy", "omni_geometry_cache_clear", "omni_geometry_cache_size",
     "omni_equi2pers", "omni_equi2pers_aux", "omni_pers2equi", "omni_pers2equi_conf",
     "omni_equi2pers_g", "omni_pers2equi_g", "omni_equi2pers_bwd", "omni_pers2equi_bwd",
     "omni_conv2d_nhwc_f32", "omni_stem_f32", "omni_maxpool3x3s2_f32", "omni_upsample_bilinear_f32",
     "omni_add_hw_f32", "omni_add_period_f32", "omni_token_pack_f32", "omni_layernorm512_f32",
     "omni_attention_f32", "omni_heads_f32", "omni_mlp_points_f32",
-    "omni_conv2d_nhwc_f16x3_ws", "omni_conv2d_sh_f16x3_ws", "omni_sh_from_f32", "omni_sh_to_f32",
+    "omni_conv2d_nhwc_f16x3_ws", "omni_conv2d_sh_f16x3_ws", "omni_sh_from_f32", "omni_sh_to_f32", "omni_sh_overflow",
     "omni_stem_sh", "omni_stem_sh_f16x3", "omni_maxpool3x3s2_sh", "omni_upsample_bilinear_sh", "omni_add_hw_sh", "omni_add_period_sh", "omni_layernorm512_sh", "omni_attention_qkv_sh",
     "omni_conv2d_splitk_plan", "omni_conv2d_nhwc_f32_ws",
     "omni_masked_median_f32", "omni_depth_metrics_f32",
@@ -58,6 +59,28 @@ def load():
         getattr(lib, name)          # AttributeError here = header/library mismatch
     _lib = lib
     return lib
+
+
+def load_debug():
+    """The DEBUG build of the library (python -m omnifusion_amd.build --debug): same entry points plus the
+    result-changing ablation switches (OMNI_*_DBG) and the omni_debug_* micro-benchmarks.  tools/ only — nothing under
+    omnifusion_amd/ or tests/ loads it."""
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH_DEBUG):
+        raise OmniLibraryMissing(f"{LIB_PATH_DEBUG} not found: python -m omnifusion_amd.build --debug")
+    lib = ctypes.CDLL(LIB_PATH_DEBUG)
+    lib.omni_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def set_option(name, value):
+    check(load().omni_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(load().omni_get_option(name.encode(), ctypes.byref(v)), "get_option")
+    return v.value
 
 
 def check(status, what=""):

@@ -22,8 +22,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-munsafe-fp-atomics", "-
          "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+LIB_DEBUG = os.path.join(CSRC, "libomnifusion_hip_dbg.so")
+DEBUG_ONLY = ("omni_debug.hip",)             # micro-benchmark scaffolding: never part of the product library
+
+
+def sources(debug=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    return srcs if debug else [f for f in srcs if os.path.basename(f) not in DEBUG_ONLY]
 
 
 def source_hash():
@@ -40,23 +45,26 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _stale(lib=LIB, debug=False):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+    t = os.path.getmtime(lib)
+    deps = sources(debug) + glob.glob(os.path.join(CSRC, "*.h")) + \
         glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=False, debug=False):
+    """debug=True builds libomnifusion_hip_dbg.so: -DOMNI_DEBUG_BUILD (result-changing ablation bits, OMNI_*_DBG) plus
+    omni_debug.hip — for tools/ only; the product library carries neither."""
+    lib = LIB_DEBUG if debug else LIB
+    if not force and not _stale(lib, debug):
+        return lib
     objs = []
     procs = []
-    for src in sources():
-        obj = src[:-4] + ".o"
-        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+    for src in sources(debug):
+        obj = src[:-4] + (".dbg.o" if debug else ".o")
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + (["-DOMNI_DEBUG_BUILD"] if debug else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -71,9 +79,9 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

@@ -59,7 +59,7 @@ struct ConvArgs {
     int f16x3;                               // 1: wt is the pre-split half format, products on the fp16 matrix cores
     int splitk;                              // >1: blockIdx.y owns a K range and writes raw partial sums to ws[y]
     float* ws;                               // [splitk][rows][Cout]
-    int dbg;                                 // OMNI_CONV_DBG ablation bits (tuning only): 1 no MFMA, 2 no refetch, 4 no stash
+    int dbg;                                 // debug build only (OMNI_CONV_DBG ablation bits): 1 no MFMA, 2 no refetch, 4 no stash
 };
 
 constexpr int BK = 32;
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256, (F16X3 ? 3 : 5)) void conv_igemm_f32_kernel(Co
     if (ks_begin < ks_end) fetch(ks_begin);
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         __syncthreads();                     // previous step's fragment reads are done
-        if (!(a.dbg & 4)) stash();
+        if (!OMNI_DBG(a, 4)) stash();
         __syncthreads();
-        if (ks + 1 < ks_end && !(a.dbg & 2)) fetch(ks + 1);  // next tiles in flight while the matrix cores work
-        if (a.dbg & 1) continue;
+        if (ks + 1 < ks_end && !OMNI_DBG(a, 2)) fetch(ks + 1);  // next tiles in flight while the matrix cores work
+        if (OMNI_DBG(a, 1)) continue;
         if (F16X3) {
             const int foff = (lane & 31) * HP + (lane >> 5) * 8;   // fragment: row lane&31, k = 8*(lane>>5) .. +7 of a 16-wide chunk
 #pragma unroll
@@ -435,7 +435,7 @@ int plan_splitk(long long rows, int Cout, int ksteps)
     long long s = (640 + blocks - 1) / blocks;
     if (s > ksteps / 4) s = ksteps / 4;
     if (s > 32) s = 32;
-    if (const char* e = getenv("OMNI_SPLITK_MAX")) { const long long cap = atoi(e); if (s > cap) s = cap; }   // tuning hook
+    if (const int cap = omni_options().splitk_max; cap > 0 && s > cap) s = cap;                                 // tuning hook
     return s < 2 ? 1 : (int)s;
 }
 }  // namespace
@@ -478,8 +478,11 @@ static int conv2d_impl(const float* src1, const float* src2, const void* wt_any,
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d: split-K workspace too small");
     a.splitk = S; a.ws = ws;
-    { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
-    if (f16x3 && S <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % HT_H == 0 && !getenv("OMNI_CONV_NOHALO")) {
+    a.dbg = 0;
+#ifdef OMNI_DEBUG_BUILD
+    a.dbg = omni_debug_bits("OMNI_CONV_DBG");
+#endif
+    if (f16x3 && S <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % HT_H == 0 && !omni_options().conv_nohalo) {
         const int grid = M * (H / HT_H) * (W / HT_W);
         if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<64>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
         else                hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<32>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);

@@ -82,7 +82,8 @@ struct ShConvArgs {
     int rows;                                // M*Ho*Wo
     int dst_sh;
     int res_f32;                             // residual is plain fp32 NHWC instead of SH
-    int dbg;                                 // OMNI_CONV_DBG (tuning): 4 = skip the epilogue
+    int dbg;                                 // debug build only (OMNI_CONV_DBG): 4 = skip the epilogue
+    int noxcd;                               // 1: identity block order (tuning, OMNI_CONV_NOXCD)
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
 };
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
     const int ntn = a.Cout / BN;
     // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous range of (tile_m, tile_n) so that the
     // blocks sharing an A row tile (and neighbouring pixels) share one L2
-    const unsigned lb = a.dbg & 8 ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned lb = a.noxcd ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = lb / ntn, tile_n = lb % ntn;
     const int row0 = tile_m * BM, col0 = tile_n * BN;
     const int G1 = a.C1 >> 5, G2 = a.C2 >> 5, G = G1 + G2;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
     }(std::make_integer_sequence<int, NST - 1>());
 
-    if (a.dbg & 4) return;
+    if (OMNI_DBG(a, 4)) return;
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / TH;
-    int bid = a.dbg & 8 ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halos, same A for all tile_n) on one XCD
+    int bid = a.noxcd ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halos, same A for all tile_n) on one XCD
     const int tile_n = bid % ntn; bid /= ntn;
     const int tx = bid % tw; bid /= tw;
     const int ty = bid % th; const int m = bid / th;
@@ -638,7 +639,10 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: bad shape (kernels up to 3x3)");
     ShConvArgs a;
     a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh; a.res_f32 = (fmt >> 1) & 1;
-    { const char* d = getenv("OMNI_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd;
+#ifdef OMNI_DEBUG_BUILD
+    a.dbg = omni_debug_bits("OMNI_CONV_DBG");
+#endif
     a.M = M; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
@@ -655,9 +659,8 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
     a.splitk = S > 1 ? S : 1; a.ws = ws;
     hipStream_t s = (hipStream_t)stream;
-    if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % 4 == 0 && !getenv("OMNI_CONV_NOHALO")) {
-        const char* he = getenv("OMNI_CONV_HALO_TH");
-        const int th = (H % 8 == 0 && (he ? atoi(he) == 8 : false)) ? 8 : 4;
+    if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % 4 == 0 && !omni_options().conv_nohalo) {
+        const int th = (H % 8 == 0 && omni_options().conv_halo_th == 8) ? 8 : 4;
         const int grid = M * (H / th) * (W / HT_W);
         if (th == 8) {
             if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 8>), dim3(grid * (Cout / 64)), dim3(512), 0, s, a);
@@ -670,8 +673,7 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
         return OMNI_OK;
     }
     // tile: results do not depend on it (every output element is the same k-ordered chain), so it is a pure tuning choice
-    int tile = 0;                                                  // 0: 64x64, 1: 128x64, 2: 128x128
-    { const char* e = getenv("OMNI_CONV_SH_TILE"); if (e) tile = atoi(e); }
+    const int tile = omni_options().conv_sh_tile;                  // -1 / 0: 64x64, 1: 128x64, 2: 128x128
     if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s);
     else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s);
     else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
@@ -679,7 +681,7 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
     // one round of at most one block per CU (the transformer GEMMs; every deep layer at batch 1): the K loop is pure latency,
     // keep 5 stages in flight instead of 2 (96 KiB of LDS, which a single resident block can afford)
-    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !getenv("OMNI_CONV_NODEEP")) launch_sh<64, 64, 2, 2, 6>(a, s);
+    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !omni_options().conv_nodeep) launch_sh<64, 64, 2, 2, 6>(a, s);
     else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
     if (a.splitk > 1) {
@@ -705,6 +707,20 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
 }
 
 // layout conversions (n = number of elements, a multiple of 32 channels per pixel)
+OMNI_SH_OVERFLOW_ACCESSOR(omni_sh_overflow_conv)          // this translation unit's copy of the sticky range flag
+int omni_sh_overflow_net(unsigned* out, int reset);      // omni_net.hip's
+
+extern "C" int omni_sh_overflow(int* flag, int reset)
+{
+    if (!flag) OMNI_FAIL(OMNI_ERR_INVALID, "omni_sh_overflow: null output");
+    OMNI_HIP(hipDeviceSynchronize());                    // diagnostic entry point, never on the hot path
+    unsigned v = 0;
+    if (omni_sh_overflow_conv(&v, reset) != 0 || omni_sh_overflow_net(&v, reset) != 0)
+        OMNI_FAIL(OMNI_ERR_HIP, "omni_sh_overflow: could not read the device flag");
+    *flag = v ? 1 : 0;
+    return OMNI_OK;
+}
+
 extern "C" int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream)
 {
     if (!src || !dst || n % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_sh_from_f32: null pointer or n % 32 != 0");

@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
 
     if (flags_out) { if (t == 0) flags_out[lb] = (fits && full) ? 0 : 1; return; }
     if (!fb_block && !(fits && full)) return;          // covered by the fallback blocks of this launch
-    if ((a.dbg & 4) && fb_block) return;
-    if ((a.dbg & 8) && !fb_block) return;
+    if (OMNI_DBG(a, 4) && fb_block) return;
+    if (OMNI_DBG(a, 8) && !fb_block) return;
     if (fb_block && blockIdx.y > 0) return;            // the fallback blocks walk every plane themselves
     if (!fb_block) {
         int r0[SPT], r1[SPT];
@@ -618,7 +618,10 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
     a.sx_scale = (float)(g->W - 1) / 2.0f; a.sy_scale = (float)(g->H - 1) / 2.0f;
     a.tab = g->e2p;
     a.ixy = g->e2p_ixy;
-    const char* d = getenv("OMNI_E2P_DBG"); a.dbg = d ? atoi(d) : 0;
+    a.dbg = 0;
+#ifdef OMNI_DEBUG_BUILD
+    a.dbg = omni_debug_bits("OMNI_E2P_DBG");
+#endif
 }
 
 }  // namespace
@@ -629,7 +632,7 @@ int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream)
     // sampling-coordinate table (8 bytes per patch sample: 9.4 MB at 18 x 256^2), read once per launch instead of two
     // transcendentals per sample and tile
     const long long total = (long long)g->N * g->ph * g->pw;
-    if (!g->e2p_ixy && total < (1ll << 28) && !getenv("OMNI_E2P_NOTAB")) {
+    if (!g->e2p_ixy && total < (1ll << 28) && !omni_options().e2p_notab) {
         OMNI_HIP(hipMalloc((void**)&g->e2p_ixy, sizeof(float2) * (size_t)total));
         hipLaunchKernelGGL(e2p_ixy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, g->e2p_ixy, (int)total);
         OMNI_HIP(hipGetLastError());
@@ -638,7 +641,6 @@ int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream)
     // tiles whose ERP footprint does not fit the LDS box are listed once per geometry and take the gather fallback
     std::vector<int> list;
     int ts = 32;
-    if (const char* te = getenv("OMNI_E2P_TS")) ts = atoi(te) == 16 ? 16 : 32;
     for (;;) {
         const int tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts;
         const int nt = g->N * tx * ty;
@@ -653,7 +655,7 @@ int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream)
         (void)hipFree(dflags);
         list.clear();
         for (int i = 0; i < nt; ++i) if (hf[i]) list.push_back(i);
-        if (getenv("OMNI_E2P_VERBOSE")) fprintf(stderr, "[omni] equi2pers %dx%d patches on %dx%d, %dx%d tiles: %d of %d take the gather fallback\n",
+        if (omni_options().e2p_verbose) fprintf(stderr, "[omni] equi2pers %dx%d patches on %dx%d, %dx%d tiles: %d of %d take the gather fallback\n",
                                                 g->ph, g->pw, g->H, g->W, ts, ts, (int)list.size(), nt);
         // (16x16 tiles — OMNI_E2P_TS=16 — cut the fallback count 3-5x where footprints are large (P = 128 at 512x1024, nrows = 6)
         //  but amortise the per-tile prologue over a quarter of the samples: measured equal or slower, so not selected automatically)
@@ -677,14 +679,11 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
     const bool pair = g->W >= 2;
     if (layout == OMNI_LAYOUT_BNCHW) {
         int spt = 2, unr = 3;
-        const char* var = getenv("OMNI_E2P_VAR");                                        // tuning hook
-        if (var) sscanf(var, "%d,%d", &spt, &unr);
-        if (sizeof(T) == 4 && !var && g->W >= 2) {
+        if (sizeof(T) == 4 && !omni_options().e2p_gather && g->W >= 2) {
             const int ts = g->e2p_ts;
             const int tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts;
             const int nt = N * tx * ty;
             int psplit = 1;                                      // plane ranges (tuning hook; splitting repeats the per-tile prologue)
-            if (const char* pe = getenv("OMNI_E2P_PSPLIT")) psplit = atoi(pe) > 0 ? atoi(pe) : 1;
             if (ts == 32) hipLaunchKernelGGL(e2p_lds_kernel<32>, dim3(nt + g->e2p_nfb * B, psplit), dim3(256), 0, stream, a, tx, tx * ty, nt,
                                              (const int*)g->e2p_fb_tiles, (unsigned char*)nullptr);
             else          hipLaunchKernelGGL(e2p_lds_kernel<16>, dim3(nt + g->e2p_nfb * B, psplit), dim3(256), 0, stream, a, tx, tx * ty, nt,
@@ -777,7 +776,7 @@ extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dty
     OMNI_HIP(hipMemsetAsync(grad_erp, 0, (size_t)B * C * H * W * sizeof(float), (hipStream_t)stream));
     const long long total = (long long)g->N * ph * pw;
     if (total >= (1ll << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers_bwd: too many patch samples");
-    if (layout == OMNI_LAYOUT_BNCHW && g->W >= 2 && !getenv("OMNI_E2P_BWD_SIMPLE")) {
+    if (layout == OMNI_LAYOUT_BNCHW && g->W >= 2 && !omni_options().e2p_bwd_simple) {
         // planar layout: the transposed LDS-box kernel (same tiling and fallback list as the forward)
         const int ts = g->e2p_ts, tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts, nt = g->N * tx * ty;
         if (ts == 32) hipLaunchKernelGGL((e2p_lds_kernel<32, true>), dim3(nt + g->e2p_nfb * B), dim3(256), 0, (hipStream_t)stream, a, tx, tx * ty, nt,

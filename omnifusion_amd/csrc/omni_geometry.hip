@@ -6,6 +6,8 @@
 // Everything here is a constant of (nrows, fov, patch size, ERP size): a few KB that
 // stay resident on the device.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 #include <memory>
@@ -16,6 +18,58 @@ static thread_local std::string g_err;
 void omni_set_error(const std::string& msg) { g_err = msg; }
 extern "C" const char* omni_last_error(void) { return g_err.c_str(); }
 extern "C" int omni_version(void) { return OMNI_VERSION; }
+
+// ---------------------------------------------------------------- options
+namespace {
+struct OptName { const char* name; const char* env; int OmniOptions::* field; int dflt; };
+const OptName kOpts[] = {
+    {"conv_sh_tile", "OMNI_CONV_SH_TILE", &OmniOptions::conv_sh_tile, -1},
+    {"conv_nohalo", "OMNI_CONV_NOHALO", &OmniOptions::conv_nohalo, 0},
+    {"conv_halo_th", "OMNI_CONV_HALO_TH", &OmniOptions::conv_halo_th, 4},
+    {"conv_nodeep", "OMNI_CONV_NODEEP", &OmniOptions::conv_nodeep, 0},
+    {"conv_noxcd", "OMNI_CONV_NOXCD", &OmniOptions::conv_noxcd, 0},
+    {"splitk_max", "OMNI_SPLITK_MAX", &OmniOptions::splitk_max, 0},
+    {"e2p_gather", "OMNI_E2P_GATHER", &OmniOptions::e2p_gather, 0},
+    {"e2p_notab", "OMNI_E2P_NOTAB", &OmniOptions::e2p_notab, 0},
+    {"e2p_verbose", "OMNI_E2P_VERBOSE", &OmniOptions::e2p_verbose, 0},
+    {"e2p_bwd_simple", "OMNI_E2P_BWD_SIMPLE", &OmniOptions::e2p_bwd_simple, 0},
+    {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
+    {"geom_cache_max", "OMNI_GEOM_CACHE_MAX", &OmniOptions::geom_cache_max, 16},
+};
+}  // namespace
+
+OmniOptions& omni_options()
+{
+    static OmniOptions o = [] {                       // thread-safe one-time initialisation (C++11 magic static)
+        OmniOptions v;
+        for (const OptName& k : kOpts) {
+            const char* e = getenv(k.env);
+            v.*(k.field) = e ? (*e ? atoi(e) : 1) : k.dflt;
+        }
+        return v;
+    }();
+    return o;
+}
+
+extern "C" int omni_set_option(const char* name, int value)
+{
+    if (!name) OMNI_FAIL(OMNI_ERR_INVALID, "omni_set_option: null name");
+    for (const OptName& k : kOpts)
+        if (strcmp(k.name, name) == 0) { omni_options().*(k.field) = value; return OMNI_OK; }
+    OMNI_FAIL(OMNI_ERR_INVALID, std::string("omni_set_option: unknown option '") + name + "'");
+}
+
+extern "C" int omni_get_option(const char* name, int* value)
+{
+    if (!name || !value) OMNI_FAIL(OMNI_ERR_INVALID, "omni_get_option: null argument");
+    for (const OptName& k : kOpts)
+        if (strcmp(k.name, name) == 0) { *value = omni_options().*(k.field); return OMNI_OK; }
+    OMNI_FAIL(OMNI_ERR_INVALID, std::string("omni_get_option: unknown option '") + name + "'");
+}
+
+#ifdef OMNI_DEBUG_BUILD
+int omni_debug_bits(const char* env_name) { const char* d = getenv(env_name); return d ? atoi(d) : 0; }
+#endif
 
 // ---------------------------------------------------------------- presets
 namespace {
@@ -144,9 +198,25 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
 }
 
 // ---------------------------------------------------------------- cache
+// LRU over (device, nrows, fov, patch size, ERP size), capped at OmniOptions::geom_cache_max handles (an entry holds the
+// device tables of its configuration, e.g. the 8 B/sample equi2pers coordinate table: inputs of ever-changing size must not
+// leak HBM).  A handle is destroyed only after its device has drained (in-flight launches may still read its tables); a
+// hit moves the entry to the front, so a handle in use is never the eviction candidate unless >= cap OTHER configurations
+// were created in between.
 namespace {
 std::mutex g_mu;
-std::vector<omni_geometry*> g_cache;
+std::vector<omni_geometry*> g_cache;           // front = most recently used
+
+void destroy_drained(omni_geometry* g)
+{
+    int cur = 0;
+    if (hipGetDevice(&cur) == hipSuccess) {
+        if (cur != g->device) (void)hipSetDevice(g->device);
+        (void)hipDeviceSynchronize();
+        if (cur != g->device) (void)hipSetDevice(cur);
+    }
+    omni_geometry_destroy(g);
+}
 }
 
 int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, float fov_w,
@@ -155,20 +225,33 @@ int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, floa
     int dev = 0;
     OMNI_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);      // replica threads (nn.DataParallel) may race here
-    for (omni_geometry* g : g_cache)
+    for (size_t i = 0; i < g_cache.size(); ++i) {
+        omni_geometry* g = g_cache[i];
         if (g->device == dev && g->nrows == nrows && g->fov_h == fov_h && g->fov_w == fov_w &&
-            g->ph == ph && g->pw == pw && g->H == H && g->W == W) { *out = g; return OMNI_OK; }
+            g->ph == ph && g->pw == pw && g->H == H && g->W == W) {
+            if (i) { g_cache.erase(g_cache.begin() + i); g_cache.insert(g_cache.begin(), g); }
+            *out = g; return OMNI_OK;
+        }
+    }
     omni_geometry* g = nullptr;
     int rc = omni_geometry_create(&g, nrows, fov_h, fov_w, ph, pw, H, W, stream);
     if (rc != OMNI_OK) return rc;
-    g_cache.push_back(g);
+    g_cache.insert(g_cache.begin(), g);
+    const size_t cap = (size_t)(omni_options().geom_cache_max > 0 ? omni_options().geom_cache_max : 1);
+    while (g_cache.size() > cap) { destroy_drained(g_cache.back()); g_cache.pop_back(); }
     *out = g;
     return OMNI_OK;
+}
+
+extern "C" int omni_geometry_cache_size(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (int)g_cache.size();
 }
 
 extern "C" void omni_geometry_cache_clear(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (omni_geometry* g : g_cache) omni_geometry_destroy(g);
+    for (omni_geometry* g : g_cache) destroy_drained(g);
     g_cache.clear();
 }

@@ -16,6 +16,35 @@ void omni_set_error(const std::string& msg);
 #define OMNI_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                   \
         omni_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return OMNI_ERR_HIP; } } while (0)
 
+// ---------------------------------------------------------------- tuning options
+// Read ONCE from the environment (OMNI_* variables, DESIGN.md "Environment switches") the first time the library needs them;
+// `omni_set_option()` (include/omnifusion.h) changes one at run time (tests and tools sweep tile shapes with it).  No option
+// changes a result bit except `splitk_max` (it changes the K summation order).  Launch paths read the struct, never getenv().
+struct OmniOptions {
+    int conv_sh_tile;     // OMNI_CONV_SH_TILE   -1 auto | 0 64x64 | 1 128x64 | 2 128x128 | 3, 4 the 8-wave forms
+    int conv_nohalo;      // OMNI_CONV_NOHALO    1: never take the halo-reuse 3x3 kernel
+    int conv_halo_th;     // OMNI_CONV_HALO_TH   rows per halo block: 4 (default) | 8
+    int conv_nodeep;      // OMNI_CONV_NODEEP    1: 3 pipeline stages even for single-round launches
+    int conv_noxcd;       // OMNI_CONV_NOXCD     1: identity block order (no XCD-aware remap)
+    int splitk_max;       // OMNI_SPLITK_MAX     cap of the split-K plan (0 = none)
+    int e2p_gather;       // OMNI_E2P_GATHER     1: equi2pers always takes the direct-gather kernel (no LDS staging)
+    int e2p_notab;        // OMNI_E2P_NOTAB      1: no per-geometry sampling-coordinate table
+    int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
+    int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 1: plain scatter backward
+    int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
+    int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
+};
+OmniOptions& omni_options();
+
+// Ablation bits that change RESULTS (skip the epilogue, suppress loads ...) exist only in the debug build of the library
+// (python -m omnifusion_amd.build --debug -> libomnifusion_hip_dbg.so, -DOMNI_DEBUG_BUILD); the product never carries them.
+#ifdef OMNI_DEBUG_BUILD
+#define OMNI_DBG(a, bit) (((a).dbg & (bit)) != 0)
+int omni_debug_bits(const char* env_name);
+#else
+#define OMNI_DBG(a, bit) false
+#endif
+
 // ---------------------------------------------------------------- geometry constants
 // Per-patch constants, passed to kernels BY VALUE (kernarg segment -> scalar loads,
 // the patch index is wave-uniform everywhere).  Trig of the fp32 centre angles is

@@ -392,6 +392,8 @@ inline int nblk(size_t n) { return (int)((n + 255) / 256); }
 }  // namespace
 
 #define S_ (hipStream_t)stream
+OMNI_SH_OVERFLOW_ACCESSOR(omni_sh_overflow_net)
+
 extern "C" {
 
 int omni_stem_f32(const float* src, const float* wt, const float* bias, float* dst, int M, int P, omni_stream_t stream)

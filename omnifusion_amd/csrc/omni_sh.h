@@ -9,14 +9,31 @@
 typedef float omni_f4v __attribute__((ext_vector_type(4)));
 typedef _Float16 omni_h4v __attribute__((ext_vector_type(4)));
 
+// Range guard: fp16(x) is inf for |x| > 65504 and the lo half would then be NaN, so values are SATURATED to the
+// fp16 range before the split (a trained checkpoint with activation outliers degrades instead of turning into NaN) and a sticky
+// per-device flag records that it happened — `omni_sh_overflow()` reads and clears it, the Python model exposes it as
+// `spherical_fusion.overflowed()`.  One copy per translation unit (the library is built without relocatable device code).
+static __device__ unsigned sh_overflow_flag;
+constexpr float SH_MAX = 65504.0f;
+
 __device__ __forceinline__ void sh_split4(const omni_f4v x, omni_h4v& hi, omni_h4v& lo)
 {
+    const float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+    if (__builtin_expect(m > SH_MAX, 0)) atomicOr(&sh_overflow_flag, 1u);           // NaN compares false: propagates like in fp32
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (fabsf(x[e]) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x[e];
-        hi[e] = h; lo[e] = (_Float16)((x[e] - (float)h) * 2048.0f);
+        const float xs = fabsf(x[e]) > SH_MAX ? copysignf(SH_MAX, x[e]) : x[e];     // NaN compares false and stays NaN
+        const _Float16 h = (fabsf(xs) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)xs;
+        hi[e] = h; lo[e] = (_Float16)((xs - (float)h) * 2048.0f);
     }
 }
+// host side of the flag, one definition per translation unit that includes this header and wants to report it
+#define OMNI_SH_OVERFLOW_ACCESSOR(fn)                                                                          \
+    int fn(unsigned* out, int reset) {                                                                         \
+        unsigned v = 0;                                                                                        \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(sh_overflow_flag), sizeof(v)) != hipSuccess) return -1;         \
+        if (reset && v) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(sh_overflow_flag), &z, sizeof(z)) != hipSuccess) return -1; } \
+        *out |= v; return 0; }
 __device__ __forceinline__ omni_f4v sh_join4(const omni_h4v hi, const omni_h4v lo)
 {
     omni_f4v x;

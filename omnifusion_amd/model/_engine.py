@@ -28,6 +28,10 @@ def split_weights_f16x3(w):
     """[Cout][K] fp32 (K % 32 == 0) -> halfs [Cout][K/32][2][32]: hi = fp16(w) (0 below the fp16 normal range),
     lo = fp16((w - hi) * 2048) — the operand format of omni_conv2d_nhwc_f16x3_ws."""
     w = w.to(torch.float32)
+    wmax = float(w.abs().max()) if w.numel() else 0.0
+    if not wmax < 65504.0:                      # also catches NaN / inf
+        raise ValueError(f"folded weight magnitude {wmax:g} is outside the fp16 range of the f16x3 operand format: "
+                         "run this checkpoint with OMNI_NET_PRECISION=fp32")
     hi = w.half()
     hi = torch.where(w.abs() < 6.103515625e-05, torch.zeros_like(hi), hi)
     lo = ((w - hi.float()) * 2048.0).half()
@@ -147,6 +151,15 @@ class Engine:
             W["point_feat"] = f(pf[:, None, None, :].expand(self.npatches, P4, P4, 64))
         self.w, self.device = W, dev
 
+    def read_overflow_flag(self, reset=True):
+        """sticky range flag of the split-half format on this engine's device (omni_sh_overflow); synchronises"""
+        if self.device is None:
+            return False
+        flag = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().omni_sh_overflow(ctypes.byref(flag), 1 if reset else 0), "sh_overflow")
+        return bool(flag.value)
+
     # ------------------------------------------------------------------ operator shims
     def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True, out_f32=False):
         """One convolution (+ folded BN, bias, residual, activation).  In the f16x3 mode the activations x, x2, res and
@@ -186,6 +199,8 @@ class Engine:
             return None, 0
         ws = getattr(self, "_ws", None)
         if ws is None or ws.numel() * 4 < nbytes or ws.device != device:
+            if ws is not None:                   # a hipGraph captured earlier (graphed()) still replays into the old buffer:
+                self._ws_retired = getattr(self, "_ws_retired", []) + [ws]       # keep it alive for the engine's lifetime
             self._ws = ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         return ws, ws.numel() * 4
 
@@ -333,15 +348,11 @@ class Engine:
         return out
 
     def check_input(self, rgb):
-        if self.w is None:
-            raise RuntimeError("no weights loaded: call load_state_dict() first")
         if not isinstance(rgb, torch.Tensor) or rgb.dim() != 4 or rgb.shape[1] != 3:
             raise ValueError("expected an RGB panorama batch [B,3,H,W]")
         if not rgb.is_cuda:
             raise ValueError("the model runs on an MI355X only (got a CPU tensor); there is no CPU path")
         if rgb.dtype != torch.float32:
             raise ValueError("float32 input expected")
-        if rgb.device != self.device:
-            raise ValueError(f"weights are on {self.device}, input on {rgb.device}")
         if _NPATCH[self.nrows] != self.npatches:
             raise ValueError("npatches does not match nrows")

@@ -1,67 +1,118 @@
 """spherical_fusion (single pass) — host-side mirror of /root/reference/model/spherical_model.py:190-314.
 
-Same class name, constructor arguments and forward signature as the reference:
+Same class name, constructor arguments and forward signature as the reference, and an `nn.Module` like it:
 
     net = spherical_fusion(nrows=4, npatches=18, patch_size=(128, 128), fov=(80, 80))
-    net.load_state_dict(ckpt)            # reference schema (5-D conv weights), 'module.' prefix optional
-    depth = net(rgb, confidence=True)    # rgb [B,3,H,W] float32 on the GPU -> [B,1,H,W]
+    net = nn.DataParallel(convert_model(net))   # test.py:105-107 (single-GPU process; see below)
+    net.load_state_dict(ckpt)                   # reference schema (5-D conv weights), 'module.' prefix optional
+    net.cuda(); net.eval()
+    depth = net(rgb, confidence=True)           # rgb [B,3,H,W] float32 on the GPU -> [B,1,H,W]
 
-The forward is a launch sequence over libomnifusion_hip.so (see _engine.py); there is no autograd
-(inference only, as test.py:197 runs the reference under torch.no_grad()).  The object is a plain
-Python class, not an nn.Module: its parameters live in packed device buffers (BN folded, NHWC-GEMM
-layouts), and the reference's nn.DataParallel wrapping (test.py:107) has no counterpart here — one
-process per GPU shards the batch instead (bench.py).
+`state_dict()` / `parameters()` / `buffers()` expose exactly the reference's 363 (iterative: 375) tensors under the
+reference's names (model/spherical_model.py:197-235): a checkpoint round-trips.  They are the MASTER copy; the forward
+runs from packed device buffers (BN folded, implicit-GEMM weight layouts, split-half operands) rebuilt lazily whenever
+the master copy changed (`load_state_dict` — also through a wrapping `nn.DataParallel` —, `.cuda()`, `.to()`).
+
+The forward is a launch sequence over libomnifusion_hip.so (see _engine.py); there is no autograd through the network
+(inference only, as test.py:197 runs the reference under torch.no_grad()): parameters have requires_grad=False and the
+module is constructed in eval mode; `train(True)` is accepted, but a forward in training mode raises (batch-statistics
+BatchNorm is not implemented).  Multi-GPU: one process per GPU shards the batch (omnifusion_amd/dist.py, bench.py);
+`nn.DataParallel` over SEVERAL devices in one process is rejected with a message, over one device it is a pass-through.
 """
+import os
+
 import torch
+from torch import nn
 
 from ._engine import Engine, strip_module_prefix
 from ..equi_pers.equi2pers_v3 import equi2pers_patches
 from .. import _lib
 from ..weights import schema
 
+_BUFFERS = ("running_mean", "running_var", "num_batches_tracked")
 
-class spherical_fusion:
+
+def _build_tree(root, sch):
+    """register the reference's parameter / buffer names on a tree of plain container modules"""
+    for name, (shape, dtype) in sch.items():
+        *path, leaf = name.split(".")
+        m = root
+        for p in path:
+            if p not in m._modules:
+                m.add_module(p, nn.Module())
+            m = m._modules[p]
+        t = torch.zeros(shape, dtype=torch.int64 if dtype == "int64" else torch.float32)
+        if leaf in _BUFFERS:
+            m.register_buffer(leaf, t)
+        else:
+            m.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+
+
+class spherical_fusion(nn.Module):
     _ITERATIVE = False
+    # Two halves of the batch on two streams.  Every layer of the network is ONE kernel whose last blocks leave most of the
+    # chip idle (the deep layers are 2.25 blocks per CU at 8 panoramas); with two independent half-batch chains in flight
+    # the scheduler fills one chain's tail with the other chain's blocks.  Results are bit-identical to the single-stream
+    # path (split-K is planned for a nominal batch, every output element is one k-ordered chain).  OMNI_LANES=1 disables.
+    LANES = int(os.environ.get("OMNI_LANES", "2"))
 
     def __init__(self, nrows=4, npatches=18, patch_size=(128, 128), fov=(80, 80)):
+        super().__init__()
         self.nrows, self.npatches, self.patch_size, self.fov = nrows, npatches, patch_size, fov
+        _build_tree(self, schema(npatches, self._ITERATIVE))
         self._eng = Engine(nrows, npatches, patch_size, fov, self._ITERATIVE)
-        self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        self.training = False
+        self._loaded = False          # a checkpoint has been loaded (the zero-initialised master copy is not a model)
+        self._dirty = True            # packed buffers are out of date w.r.t. the master copy
+        self._lanes = None
+        self.training = False         # inference module: constructed in eval mode
+        self.register_load_state_dict_post_hook(spherical_fusion._after_load)
 
-    # ---- nn.Module-flavoured conveniences the reference scripts use
-    def eval(self):
-        return self
+    # ---- master copy <-> packed buffers
+    @staticmethod
+    def _after_load(module, incompatible_keys):
+        # fires for a direct load_state_dict() AND when a wrapper (nn.DataParallel, test.py:107-110) loads through us
+        if not incompatible_keys.missing_keys:
+            module._loaded = True
+        module._dirty = True
 
-    def cuda(self, device=None):
-        self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        if getattr(self, "_sd", None) is not None:
-            self._eng.pack(self._sd, self._device)
-        return self
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        sd = strip_module_prefix(state_dict)                               # train_erp_depth.py:307 saves through DataParallel
+        sd = {k: v for k, v in sd.items() if not k.endswith("total_ops") and not k.endswith("total_params")}   # thop residue
+        return super().load_state_dict(sd, strict=strict, assign=assign)
 
-    def to(self, device):
-        return self.cuda(torch.device(device).index)
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._dirty = True                                                 # .cuda() / .to(): repack on the new device
+        return out
 
     def state_dict_schema(self):
         return schema(self.npatches, self._ITERATIVE)
 
-    def load_state_dict(self, state_dict, strict=True):
-        sd = strip_module_prefix(state_dict)
-        want = self.state_dict_schema()
-        missing = [k for k in want if k not in sd and not k.endswith("num_batches_tracked")]
-        if missing and strict:
-            raise RuntimeError(f"missing keys in state_dict: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
-        for k, (shape, _) in want.items():
-            if k in sd and tuple(sd[k].shape) != tuple(shape):
-                raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shape)}")
-        self._sd = sd
-        if self._device is None:
-            raise RuntimeError("no MI355X visible: this model has no CPU path")
-        self._eng.pack(sd, self._device)
-        return self
+    def _master_device(self):
+        return self.conv1.weight.device
 
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
+    def _sync_packed(self, rgb_device):
+        """rebuild the packed device buffers if the master copy changed; all lanes (execution contexts) follow"""
+        if not self._loaded:
+            raise RuntimeError("no weights loaded: call load_state_dict() first")
+        dev = self._master_device()
+        if dev.type != "cuda":
+            raise RuntimeError(f"the model's parameters are on {dev}: move it to an MI355X with .cuda() — there is no CPU path")
+        if self._dirty or self._eng.device != dev:
+            self._eng.pack(super().state_dict(), dev)
+            self._lanes = None                                             # lanes alias the packed weights: rebuild them
+            self._dirty = False
+        if rgb_device != dev:
+            hint = ""
+            if torch.cuda.device_count() > 1:
+                hint = " (nn.DataParallel over several devices in one process is not supported: run one process per GPU, omnifusion_amd/dist.py)"
+            raise ValueError(f"weights are on {dev}, input on {rgb_device}{hint}")
+
+    def overflowed(self):
+        """True if any activation left the range the split-half fp16 format represents (|x| > 65504) since the last call.
+        Reads a device flag (synchronises).  The f16x3 path saturates such values instead of producing inf/NaN; rerun with
+        OMNI_NET_PRECISION=fp32 for a checkpoint that trips this."""
+        return self._eng.read_overflow_flag()
 
     def graphed(self, example, *args, **kwargs):
         """Capture one forward for inputs shaped like `example` into a hipGraph and return `run(rgb) -> output`.
@@ -85,33 +136,35 @@ class spherical_fusion:
         run.graph = g
         return run
 
+    def _check(self, rgb):
+        if self.training:
+            raise NotImplementedError("spherical_fusion is inference-only (eval-mode BatchNorm folded into the weights): call .eval()")
+        self._eng.check_input(rgb)
+        self._sync_packed(rgb.device)
+
     @torch.no_grad()
     def forward(self, rgb, confidence=True):
+        self._check(rgb)
         e = self._eng
-        e.check_input(rgb)
         bs, _, H, W = rgb.shape
         with torch.cuda.device(rgb.device):
             patches = equi2pers_patches(rgb, self.fov, self.nrows, self.patch_size, layout=_lib.LAYOUT_BNCHW)   # :243
             a, c = self.network(patches, bs, confidence)                                                        # :245-306
             return e.blend(a, c, (H, W))                                                                        # :307-313
 
-    def network(self, patches, bs, confidence):
+    def network(self, patches, bs, confidence, point_feat=None):
         """planar patches [bs,N,3,P,P] -> (pred * conf, conf) planes [bs,N,1,P,P] (the part of forward between the two resamplers)"""
         e = self._eng
+        if self._dirty or e.w is None:
+            self._sync_packed(patches.device)
+        pf = e.w["point_feat"] if point_feat is None else point_feat
         if bs < 2 * self.LANES or self.LANES < 2:
-            return e.network(patches, e.w["point_feat"], bs, confidence)
-        return self._network_lanes(patches, bs, confidence)
+            return e.network(patches, pf, bs, confidence)
+        return self._network_lanes(patches, pf, bs, confidence)
 
-    # Two halves of the batch on two streams.  Every layer of the network is ONE kernel whose last blocks leave most of the
-    # chip idle (the deep layers are 2.25 blocks per CU at 8 panoramas); with two independent half-batch chains in flight
-    # the scheduler fills one chain's tail with the other chain's blocks.  Results are bit-identical to the single-stream
-    # path (split-K is planned for a nominal batch, every output element is one k-ordered chain).  OMNI_LANES=1 disables.
-    import os as _os
-    LANES = int(_os.environ.get("OMNI_LANES", "2"))
-
-    def _network_lanes(self, patches, bs, confidence):
+    def _network_lanes(self, patches, pf, bs, confidence):
         e = self._eng
-        if getattr(self, "_lanes", None) is None or self._lanes[0][0].w is not e.w:
+        if self._lanes is None:                                            # reset by _sync_packed whenever the weights were repacked
             self._lanes = [(e, None)] + [(e.lane(), torch.cuda.Stream(device=patches.device)) for _ in range(self.LANES - 1)]
         N, P = self.npatches, e.patch_size[0]
         a = torch.empty((bs, N, 1, P, P), dtype=torch.float32, device=patches.device)
@@ -119,18 +172,20 @@ class spherical_fusion:
         cur = torch.cuda.current_stream(patches.device)
         fork = cur.record_event()
         per = (bs + self.LANES - 1) // self.LANES
+        per_item = pf.shape[0] == bs * N                                   # iterative model: one feature map per (panorama, patch)
         joins = []
         for k, (eng, stream) in enumerate(self._lanes):
             lo, hi = k * per, min(bs, (k + 1) * per)
             if lo >= hi:
                 break
             out = (a[lo:hi], c[lo:hi] if confidence else None)
+            pfk = pf[lo * N:hi * N] if per_item else pf
             if stream is None:
-                eng.network(patches[lo:hi], e.w["point_feat"], hi - lo, confidence, out=out)
+                eng.network(patches[lo:hi], pfk, hi - lo, confidence, out=out)
             else:
                 stream.wait_event(fork)
                 with torch.cuda.stream(stream):
-                    eng.network(patches[lo:hi], e.w["point_feat"], hi - lo, confidence, out=out)
+                    eng.network(patches[lo:hi], pfk, hi - lo, confidence, out=out)
                     joins.append(stream.record_event())
         for ev in joins:
             cur.wait_event(ev)

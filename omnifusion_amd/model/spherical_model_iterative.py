@@ -23,8 +23,8 @@ class spherical_fusion(_single):
 
     @torch.no_grad()
     def forward(self, high_res, iter, confidence=False):
+        self._check(high_res)
         e = self._eng
-        e.check_input(high_res)
         bs, _, H, W = high_res.shape
         P = e.patch_size[0]
         p4 = (P // 4, P // 4)
@@ -32,11 +32,11 @@ class spherical_fusion(_single):
             patches = equi2pers_patches(high_res, self.fov, self.nrows, self.patch_size, layout=_lib.LAYOUT_BNCHW)   # :315 (= :384)
             xyz, _, _ = equi2pers_aux(high_res.device, self.fov, self.nrows, p4, want_xyz=True, want_uv=False)       # :316
             pf = e.mlp_points("mlp_points1", xyz, None, self.npatches)                                               # :319
-            a, c = e.network(patches, pf, bs, confidence)
+            a, c = self.network(patches, bs, confidence, point_feat=pf)
             outs = [e.blend(a, c, (H, W))]                                                                           # :371-380
             for i in range(iter - 1):                                                                                # :383
                 depth = equi2pers_patches(outs[i], self.fov, self.nrows, p4, layout=_lib.LAYOUT_BNCHW)               # :385 [B,N,1,p,p]
                 pf = e.mlp_points("mlp_points2", xyz, depth, bs * self.npatches)                                     # :387-393
-                a, c = e.network(patches, pf, bs, confidence)
+                a, c = self.network(patches, bs, confidence, point_feat=pf)
                 outs.append(e.blend(a, c, (H, W)))                                                                   # :444-454
         return outs

@@ -29,12 +29,34 @@ def test_header_symbols_exported_and_bound():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/omnifusion.h but not exported"
     assert sorted(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ set(declared)
-    assert L.omni_version() == 100
+    assert L.omni_version() == 200
     assert [L.omni_num_patches(n) for n in (3, 4, 5, 6, 7)] == [10, 18, 26, 46, -1]
     cp = (ctypes.c_float * 36)()
     assert L.omni_patch_centers(4, 0, cp) == 0 and abs(cp[0] + 2 / 3) < 1e-6 and cp[1] == -0.75
     assert L.omni_patch_centers(9, 0, cp) == _lib.OMNI_ERR_INVALID
     assert b"nrows" in L.omni_last_error()
+
+
+def test_options_and_no_debug_switches_in_product():
+    """Tuning options go through omni_set_option / OMNI_* variables read once (no getenv on launch paths); the ablation
+    switches that change results and the omni_debug_* micro-benchmarks exist only in the debug build (VERDICT r1 #13)."""
+    from omnifusion_amd import _lib
+    L = _lib.load()
+    assert _lib.get_option("conv_sh_tile") == -1 and _lib.get_option("geom_cache_max") == 16
+    _lib.set_option("conv_sh_tile", 2)
+    assert _lib.get_option("conv_sh_tile") == 2
+    _lib.set_option("conv_sh_tile", -1)
+    with pytest.raises(ValueError, match="unknown option"):
+        _lib.set_option("no_such_option", 1)
+    for name in ("omni_debug_fill", "omni_debug_dma_probe", "omni_debug_dma_rate"):
+        assert not hasattr(L, name), f"{name} exported by the product library"
+    csrc = os.path.join(ROOT, "omnifusion_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip") and f not in ("omni_debug.hip", "omni_geometry.hip"):
+            txt = open(os.path.join(csrc, f)).read()
+            assert "getenv" not in txt, f"{f}: getenv() outside the one-time option table"
+    geo = open(os.path.join(csrc, "omni_geometry.hip")).read()
+    assert geo.count("getenv(") == 2          # the option table initialiser + the debug-build helper
 
 
 def test_product_never_imports_oracle():
@@ -63,10 +85,11 @@ def test_no_cpu_fallback():
         pers2equi(torch.zeros(1, 1, 8, 8, 18), 80, 4, 8, (16, 32), "x")
     with pytest.raises(ValueError):
         equi2pers(torch.zeros(1, 3, 8, 16), 80, 7, 8)
+    from omnifusion_amd.weights import make_state_dict
     net = spherical_fusion()
-    with pytest.raises(RuntimeError, match="no CPU path"):
-        from omnifusion_amd.weights import make_state_dict
-        net.load_state_dict(make_state_dict(1, 18, False))
+    net.load_state_dict(make_state_dict(1, 18, False))            # the master copy is plain nn.Module state: loads anywhere
+    with pytest.raises(ValueError, match="no CPU path"):          # ... but there is nothing to run it on
+        net(torch.zeros(1, 3, 32, 64))
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -100,8 +100,8 @@ def test_conv2d_vs_torch(cfg):
     assert lib.omni_sh_to_f32(_p(S1), _p(back), n32(X1), _stream()) == 0
     assert (back - X1).abs().max().item() <= 2.0 ** -22 * X1.abs().max().item()
     try:
-        for tile in ("0", "1", "2", "3", "4"):
-            os.environ["OMNI_CONV_SH_TILE"] = tile
+        for tile in (0, 1, 2, 3, 4):
+            L.set_option("conv_sh_tile", tile)
             for S in (1, min(3, ksteps)):
                 for dst_sh in (0, 1):
                     ws = torch.empty(S * out.numel(), device=DEV)
@@ -115,7 +115,7 @@ def test_conv2d_vs_torch(cfg):
                         osh = o32
                     assert (osh.cpu().double() - ref).abs().max().item() < 3e-5, (tile, S, dst_sh)
     finally:
-        os.environ.pop("OMNI_CONV_SH_TILE", None)
+        L.set_option("conv_sh_tile", -1)
 
 
 def test_sh_elementwise_ops_match_f32():
@@ -329,3 +329,123 @@ def test_model_errors():
     net256.load_state_dict(make_state_dict(42, 18, True))
     with pytest.raises(RuntimeError):
         net256(torch.zeros(1, 3, 64, 128, device=DEV), 1)
+
+
+# ------------------------------------------------------------------ round-2 regressions (ADVICE r1)
+def test_reload_weights_refreshes_every_lane():
+    """ADVICE r1 (high): after a second load_state_dict() on a model that already ran a batch >= 4, lane 1 (the second
+    half-batch stream) must run the NEW weights.  Compare against a single-lane run of the same model."""
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    rgb = torch.rand((4, 3, 64, 128), generator=torch.Generator().manual_seed(3)).to(DEV)
+    net.load_state_dict(make_state_dict(1, 18, False))
+    a = net(rgb).clone()
+    net.load_state_dict(make_state_dict(2, 18, False))
+    b = net(rgb).clone()
+    try:
+        spherical_fusion.LANES = 1
+        b1 = net(rgb).clone()
+        net.load_state_dict(make_state_dict(1, 18, False))
+        a1 = net(rgb).clone()
+    finally:
+        spherical_fusion.LANES = 2
+    assert torch.equal(b, b1) and torch.equal(a, a1)
+    assert not torch.equal(a[2:], b[2:])                  # the second half really depends on the checkpoint
+
+
+def test_module_moves_and_dataparallel_wrapper():
+    """test.py:104-111 literally: construct -> DataParallel -> load_state_dict (module.-prefixed) -> cuda -> eval -> call"""
+    from torch import nn
+    spherical_fusion, _, make_state_dict = _nets()
+    g = golden("G6_model_single")
+    net = nn.DataParallel(spherical_fusion(4, 18, (128, 128), (80, 80)), device_ids=[0])
+    net.load_state_dict({"module." + k: v for k, v in make_state_dict(42, 18, False).items()})
+    net.cuda()
+    net.eval()
+    out = net(torch.from_numpy(g["rgb"]).to(DEV), confidence=True)
+    assert np.abs(out.cpu().numpy() - g["depth_conf"]).max() <= 1e-3
+    inner = net.module
+    assert inner.state_dict()["conv1.weight"].is_cuda
+    # .to(device) with a torch.device / string, and a CPU master copy fails loudly at forward time
+    inner.to("cuda:0"); inner.to(torch.device("cuda", 0))
+    assert torch.equal(inner(torch.from_numpy(g["rgb"]).to(DEV)), out)
+    inner.to("cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        inner(torch.from_numpy(g["rgb"]).to(DEV))
+    inner.cuda()
+    assert torch.equal(inner(torch.from_numpy(g["rgb"]).to(DEV)), out)
+
+
+def test_model_golden_fp32_precision_mode(monkeypatch):
+    """README/DESIGN claim both precision modes pass the same golden: OMNI_NET_PRECISION=fp32 at MODEL level (VERDICT r1 weak #4)"""
+    monkeypatch.setenv("OMNI_NET_PRECISION", "fp32")
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    g = golden("G6_model_single")
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    assert net._eng.precision == "fp32"
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rgb = torch.from_numpy(g["rgb"]).to(DEV)
+    assert np.abs(net(rgb, confidence=True).cpu().numpy() - g["depth_conf"]).max() <= 1e-3
+    assert np.abs(net(rgb, confidence=False).cpu().numpy() - g["depth_noconf"]).max() <= 1e-3
+    g7 = golden("G7_model_iterative")
+    net = spherical_fusion_it(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, True))
+    o = net(torch.from_numpy(g7["rgb"]).to(DEV), iter=2)
+    assert np.abs(o[1].cpu().numpy() - g7["it1"]).max() <= 1e-3
+
+
+def test_sh_range_guard_and_large_magnitudes():
+    """ADVICE r1 (medium): the split-half format saturates |x| > 65504 instead of producing inf/NaN and raises a sticky flag;
+    large but representable magnitudes keep fp32-class RELATIVE accuracy through an f16x3 convolution."""
+    L, lib = _lib()
+    n = lambda t: ctypes.c_size_t(t.numel())
+    flag = ctypes.c_int(0)
+    assert lib.omni_sh_overflow(ctypes.byref(flag), 1) == 0                       # clear
+    x = torch.tensor([1e5, -3e7, 65504.0, 70000.0, float("nan"), 1.0, -2.5, 6e4] * 8, device=DEV)
+    sh = torch.empty_like(x); back = torch.empty_like(x)
+    assert lib.omni_sh_from_f32(_p(x), _p(sh), n(x), _stream()) == 0
+    assert lib.omni_sh_to_f32(_p(sh), _p(back), n(x), _stream()) == 0
+    b = back.cpu()[:8]
+    assert b[0] == 65504.0 and b[1] == -65504.0 and b[2] == 65504.0 and b[3] == 65504.0 and torch.isnan(b[4])
+    assert b[5] == 1.0 and b[6] == -2.5 and abs(b[7].item() - 6e4) < 0.02
+    assert lib.omni_sh_overflow(ctypes.byref(flag), 1) == 0 and flag.value == 1   # raised, then cleared by reset
+    assert lib.omni_sh_overflow(ctypes.byref(flag), 0) == 0 and flag.value == 0
+    # conv on activations ~ 2e4 (outputs ~ 3e4): relative error stays at the 1e-6 level
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    g = torch.Generator().manual_seed(5)
+    M, H, W, C, Co = 2, 16, 16, 64, 64
+    x1 = torch.randn(M, H, W, C, generator=g) * 2e4
+    w = torch.randn(Co, C, 3, 3, generator=g) / np.sqrt(C * 9)
+    ref = F.conv2d(x1.permute(0, 3, 1, 2).double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
+    wt = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    X = x1.to(DEV); XS = torch.empty_like(X)
+    assert lib.omni_sh_from_f32(_p(X), _p(XS), n(X), _stream()) == 0
+    out = torch.empty((M, H, W, Co), device=DEV)
+    rc = lib.omni_conv2d_sh_f16x3_ws(_p(XS), None, _p(split_weights_f16x3(wt).to(DEV)), None, None, _p(out), 0, M, H, W, C, 0, Co,
+                                     3, 3, 1, 1, 0, 1, None, ctypes.c_size_t(0), _stream())
+    assert rc == 0, lib.omni_last_error()
+    assert (out.cpu().double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert lib.omni_sh_overflow(ctypes.byref(flag), 1) == 0 and flag.value == 0
+    with pytest.raises(ValueError, match="fp16 range"):
+        split_weights_f16x3(torch.full((32, 32), 7e4))
+
+
+def test_geometry_cache_is_bounded():
+    """ADVICE r1 (low): inputs of ever-changing size must not leak device tables — LRU capped at geom_cache_max"""
+    L, lib = _lib()
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
+    lib.omni_geometry_cache_clear()
+    L.set_option("geom_cache_max", 4)
+    try:
+        outs = []
+        for k in range(9):
+            x = torch.rand((1, 1, 32 + 2 * k, 64), device=DEV)
+            outs.append(equi2pers_patches(x, 80, 4, 8))
+            assert lib.omni_geometry_cache_size() <= 4
+        assert lib.omni_geometry_cache_size() == 4
+        x0 = torch.rand((1, 1, 32, 64), device=DEV)                  # an evicted configuration is simply rebuilt
+        a = equi2pers_patches(x0, 80, 4, 8); b = equi2pers_patches(x0, 80, 4, 8)
+        assert torch.equal(a, b)
+    finally:
+        L.set_option("geom_cache_max", 16)
+        lib.omni_geometry_cache_clear()

@@ -1,7 +1,7 @@
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 from omnifusion_amd import _lib
-lib = _lib.load()
+lib = _lib.load_debug()
 src = torch.arange(1024, dtype=torch.float32, device="cuda") + 1
 offs = torch.arange(64, dtype=torch.int32) * 16
 offs[5] = -2147483648; offs[9] = 4096; offs[17] = 1 << 30; offs[63] = 4080

@@ -1,7 +1,7 @@
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 from omnifusion_amd import _lib
-lib = _lib.load()
+lib = _lib.load_debug()
 src = torch.randn(1 << 20, device="cuda")          # 4 MiB: L2 / MALL resident
 sink = torch.zeros(4, device="cuda")
 P = lambda t: ctypes.c_void_p(t.data_ptr())

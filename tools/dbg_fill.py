@@ -1,7 +1,7 @@
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 from omnifusion_amd import _lib
-lib = _lib.load()
+lib = _lib.load_debug()
 n = 18 * 256 * 256          # one "plane" = all patches of one (b,c)
 for planes in (1, 24):
     buf = torch.empty(n * planes, device="cuda")

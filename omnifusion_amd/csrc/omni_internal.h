@@ -32,6 +32,9 @@ struct OmniOptions {
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
     int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 1: plain scatter backward
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
+    int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
+    int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
+    int p2e_bpc;          // OMNI_P2E_BPC        persistent blocks per CU of the pers2equi LDS kernel: 0 = what the occupancy API reports
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
 OmniOptions& omni_options();
@@ -71,6 +74,10 @@ struct omni_geometry {
     float2* col_trig;              // [W]  (sin lon_j, cos lon_j)
     unsigned long long* cand;      // [H][ntx] bit n set <=> patch n covers >=1 pixel of the 64-px tile
     int ntx;
+    // pers2equi LDS path: per ERP tile (P2E_TH x P2E_TW pixels) the list of covering patches with the bounding box of their
+    // bilinear taps inside the patch (omni_pers2equi.hip); index 0: 4-byte elements, 1: 2-byte elements (16-byte chunk alignment)
+    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; } p2e_tiles[2];
+    int p2e_tx, p2e_ty;            // tiles per ERP row / column
     int* e2p_fb_tiles;             // equi2pers: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box
     int e2p_nfb;
     int e2p_ts;                    // equi2pers: tile side (32 or 16 samples) chosen so that the footprints fit the LDS box
@@ -82,6 +89,8 @@ int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, floa
                          int ph, int pw, int H, int W, hipStream_t stream);
 // implemented in omni_pers2equi.hip: fills g->cand on `stream`
 int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream);
+// implemented in omni_pers2equi.hip: fills g->p2e_tiles (needs g->cand)
+int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream);
 // implemented in omni_equi2pers.hip: fills g->e2p_fb_tiles / e2p_nfb
 int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream);
 
@@ -106,4 +115,26 @@ __device__ __forceinline__ unsigned omni_xcd_remap(unsigned bid, unsigned nblock
     const unsigned full = per << 3;
     if (bid >= full) return bid;                       // ragged tail keeps identity
     return (bid & 7u) * per + (bid >> 3);
+}
+
+// Band-interleaved XCD map for kernels tiled over the ERP image.  ERP tile rows differ in cost (a polar row is covered by 3-4
+// patches, an equatorial row by 2): one contiguous latitude range per XCD leaves the polar XCDs with ~1.6x the work of the
+// equatorial ones.  But vertically adjacent tiles share most of their gather footprint, and only tiles on ONE XCD share an L2
+// (interleaving single tile rows measured 3.6x the compulsory HBM traffic).  So the image is cut into bands of `band` tile rows,
+// XCD x (blocks = x mod 8) owns bands x, x+8, x+16, ... and walks each band row by row.
+// Launch omni_xcd_bands_grid() blocks; false = padding block (row past the end).
+__host__ __device__ inline int omni_xcd_band_rows(int rows) { const int b = rows / 32; return b < 1 ? 1 : (b > 8 ? 8 : b); }
+__host__ __device__ inline int omni_xcd_rows_grid(int rows, int cols)
+{
+    const int band = omni_xcd_band_rows(rows);
+    return 8 * ((rows + 8 * band - 1) / (8 * band)) * band * cols;
+}
+__device__ __forceinline__ bool omni_xcd_rows(unsigned bid, int rows, int cols, int& row, int& col)
+{
+    const int band = omni_xcd_band_rows(rows);
+    const unsigned x = bid & 7u, k = bid >> 3, per = (unsigned)(band * cols);
+    const unsigned bl = k / per, wi = k - bl * per;                // band index within this XCD's list, tile within the band
+    row = (int)((bl * 8u + x) * (unsigned)band + wi / (unsigned)cols);
+    col = (int)(wi % (unsigned)cols);
+    return row < rows;
 }

@@ -23,6 +23,8 @@
 // host:  cos(lon-l0) = cos lon cos l0 + sin lon sin l0  etc.  No transcendental in the kernel.
 //
 // HBM-bound: algorithmic bytes B*C*(ph*pw*N + H*W)*sizeof(T); tables read: 8 B per tile.
+#include <stdio.h>
+#include <utility>
 #include "omni_internal.h"
 
 namespace {
@@ -36,6 +38,7 @@ struct P2EArgs {
     long long sB, sC, sN, sY, sX;              // element strides of the patch tensor
     float kx, ky;                              // 1/(FOVx*PI), 1/(FOVy*PI_2)   (:115-116)
     float half_h, half_w;                      // 0.5*height, 0.5*width        (:122-123)
+    int dbg;                                   // debug build only (OMNI_P2E_DBG ablation bits): 1 no tap geometry, 2 no LDS tap reads, 4 no DMA, 8 no stores
     PatchTab tab;
 };
 
@@ -43,14 +46,24 @@ struct Taps { int x0, x1, y0, y1; float wa, wb, wc, wd; };
 
 
 // pers2equi_v3.py:112-152 + :191 for one (pixel, patch).  Returns the validity mask.
-__device__ __forceinline__ bool p2e_taps(const P2EArgs& a, int n, float slat, float clat, float slon, float clon, Taps& t)
+// Split in two so that the pixels of one ERP column (same lon) share cos/sin(lon - l0); every kernel (candidate masks, tile
+// boxes, gather blend, LDS blend) goes through these SAME two functions, so all of them see the same bits.
+__device__ __forceinline__ void p2e_lon(const P2EArgs& a, int n, float slon, float clon, float& cd, float& sd)
 {
-    const float sl0 = a.tab.slam[n], cl0 = a.tab.clam[n], sp = a.tab.sphi[n], cp = a.tab.cphi[n];
-    const float cd = clon * cl0 + slon * sl0;                       // cos(lon - l0)
-    const float sd = slon * cl0 - clon * sl0;                       // sin(lon - l0)
+    const float sl0 = a.tab.slam[n], cl0 = a.tab.clam[n];
+    cd = clon * cl0 + slon * sl0;                                   // cos(lon - l0)
+    sd = slon * cl0 - clon * sl0;                                   // sin(lon - l0)
+}
+__device__ __forceinline__ bool p2e_taps_cs(const P2EArgs& a, int n, float slat, float clat, float cd, float sd, Taps& t)
+{
+    const float sp = a.tab.sphi[n], cp = a.tab.cphi[n];
     const float cos_c = sp * slat + cp * clat * cd;                 // :112
-    float nx = (clat * sd) / cos_c;                                 // :113
-    float ny = (cp * slat - sp * clat * cd) / cos_c;                // :114
+    // :113-114 divide twice by cos_c; one reciprocal and two products differ from that by <= 2 ulp of X, Y (a
+    // validity / floor predicate can flip only where the reference's own coordinate is within round-off of the step)
+    float rc = __builtin_amdgcn_rcpf(cos_c);                       // 1 ulp ...
+    rc = fmaf(fmaf(-cos_c, rc, 1.0f), rc, rc);                      // ... + one Newton step: ~0.5 ulp (an IEEE division costs 11 instructions)
+    float nx = (clat * sd) * rc;                                    // :113
+    float ny = (cp * slat - sp * clat * cd) * rc;                   // :114
     nx = nx * a.kx;                                                 // :115
     ny = ny * a.ky;                                                 // :116
     const float X = (nx + 1.0f) * a.half_h;                         // :122 (sic)
@@ -58,19 +71,35 @@ __device__ __forceinline__ bool p2e_taps(const P2EArgs& a, int n, float slat, fl
     const float fw = (float)a.pw, fh = (float)a.ph;
     const bool valid = (X < fw) && (X > 0.0f) && (Y < fh) && (Y > 0.0f) && (cos_c > 0.0f);   // :118,126-127
     const float fx = floorf(X), fy = floorf(Y);                     // :129-132
-    const float x0f = fminf(fmaxf(fx, 0.0f), fw - 1.0f), x1f = fminf(fmaxf(fx + 1.0f, 0.0f), fw - 1.0f);   // :134-137
-    const float y0f = fminf(fmaxf(fy, 0.0f), fh - 1.0f), y1f = fminf(fmaxf(fy + 1.0f, 0.0f), fh - 1.0f);
+    // :134-137 clamp x0, x1, y0, y1 to [0, P-1].  A VALID pixel has 0 < X < P, so floor(X) is already in range and only the +1
+    // taps can leave it (at the far edge); for an invalid pixel every weight is zeroed below and no kernel uses its indices.
+    const float x0f = fx, x1f = fminf(fx + 1.0f, fw - 1.0f);
+    const float y0f = fy, y1f = fminf(fy + 1.0f, fh - 1.0f);
     float wa = (x1f - X) * (y1f - Y);                               // :139  tap (y0,x0)
     float wb = (x1f - X) * (Y - y0f);                               // :140  tap (y1,x0)
     float wc = (X - x0f) * (y1f - Y);                               // :141  tap (y0,x1)
     float wd = (X - x0f) * (Y - y0f);                               // :142  tap (y1,x1)
     // :144-147 multiply by mask, :191 zero everything <= 1e-5
-    t.wa = (valid && wa > 1e-5f) ? wa : 0.0f;
-    t.wb = (valid && wb > 1e-5f) ? wb : 0.0f;
-    t.wc = (valid && wc > 1e-5f) ? wc : 0.0f;
-    t.wd = (valid && wd > 1e-5f) ? wd : 0.0f;
+    wa = valid ? wa : 0.0f; wb = valid ? wb : 0.0f; wc = valid ? wc : 0.0f; wd = valid ? wd : 0.0f;
+    t.wa = wa > 1e-5f ? wa : 0.0f;
+    t.wb = wb > 1e-5f ? wb : 0.0f;
+    t.wc = wc > 1e-5f ? wc : 0.0f;
+    t.wd = wd > 1e-5f ? wd : 0.0f;
+    // Right patch edge (x1 == x0 == pw-1, X in [pw-1, pw)): the x0 taps carry the factor (x1 - X) <= 0, so wa and wb are already
+    // exactly 0 — except in the corner cell, where y is clamped too and wa = (x1-X)(y1-Y) > 0.  There all four taps are the same
+    // pixel; its weight is moved to the (y1, x1) tap (v*wa + v*wd -> v*(wa + wd): one rounding), so that EVERY kernel may assume
+    // "x1 == x0  =>  wa == wb == 0" and read the tap pair one column to the left without a select.
+    const bool xedge = x1f == x0f;
+    t.wd = xedge ? t.wd + t.wa : t.wd;
+    t.wa = xedge ? 0.0f : t.wa;
     t.x0 = (int)x0f; t.x1 = (int)x1f; t.y0 = (int)y0f; t.y1 = (int)y1f;
     return valid;
+}
+__device__ __forceinline__ bool p2e_taps(const P2EArgs& a, int n, float slat, float clat, float slon, float clon, Taps& t)
+{
+    float cd, sd;
+    p2e_lon(a, n, slon, clon, cd, sd);
+    return p2e_taps_cs(a, n, slat, clat, cd, sd, t);
 }
 
 // One wave per 64-pixel tile: bit n of cand[row][tile] = any lane valid for patch n.
@@ -127,10 +156,10 @@ template <typename T, int PL, bool CONF, bool XS1>
 __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4, int nblocks)
 {
     // block = 4 waves = 4 consecutive rows x 64 columns (vertical neighbours share gather lines in L1)
-    const unsigned lb = omni_xcd_remap(blockIdx.x, nblocks);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tx = lb % a.ntx;
-    const int i = __builtin_amdgcn_readfirstlane((int)(lb / a.ntx) * 4 + wave);   // wave-uniform row
+    int r4, tx;
+    if (!omni_xcd_rows(blockIdx.x, tiles_per_row4, a.ntx, r4, tx)) return;        // tiles_per_row4 = groups of 4 rows
+    const int i = __builtin_amdgcn_readfirstlane(r4 * 4 + wave);                   // wave-uniform row
     const int j = tx * 64 + lane;
     if (i >= a.H) return;
     const bool inside = j < a.W;
@@ -225,6 +254,291 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
     }
 }
 
+
+// ------------------------------------------------------------------ LDS-staged blend (planar layout)
+// The gather kernel above is bound by the vector L1 (a 64-lane gather of 8-byte pairs costs ~20 tag look-ups for 0.5 KB of
+// useful data, profiles/r01f_resample_pmc.txt), not by HBM.  Here ONE WAVE owns an ERP tile of P2E_TH x P2E_TW pixels (4 per
+// lane) and, per covering patch and image plane, streams the bounding box of the tile's bilinear taps inside the patch into
+// LDS with 16-byte LDS-DMA pieces (global_load_lds: 64 useful bytes per L1 access, no VGPR staging, no ds_write) and takes the
+// taps from LDS.  Boxes are constants of the geometry: a per-tile table (patch, origin, size) is built once per handle by the
+// SAME tap function the blend uses (exact superset by construction), so the blend itself has no reduction, no barrier and no
+// block-level synchronisation at all — a wave orders its own DMA -> ds_read hand-off with counted `s_waitcnt vmcnt(N)`, and
+// keeps `nbuf` boxes in flight (ring of equal slots, sized for the largest box of the geometry).  Arithmetic, summation order
+// and therefore every output bit are those of the gather kernel (tests compare the two with torch.equal).
+constexpr int P2E_TH = 4, P2E_TW = 32;          // ERP tile of one wave: NPX = TH/2 pixels per lane (lane -> column lane%32, rows lane/32 + 2k)
+constexpr int P2E_NPX = P2E_TH / 2;
+constexpr int P2E_MAXC = 12;                    // table entries (covering patches) per tile
+constexpr int P2E_NJMAX = 8;                    // 1-KiB DMA pieces per box at most: boxes up to 8 KiB
+constexpr int P2E_MAX_CHUNKS = 64 * P2E_NJMAX;
+
+// entry: x = n | bw4 << 6 | bh << 16 | (entry 0 only) count << 26 (bw4 = 16-byte chunks per box row, bh = box rows, both <= 512;
+// count = covering patches of the tile), y = xa | ymin << 16
+__global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __restrict__ ent, int tiles_x, int ntiles, int epc,
+                                                        int* __restrict__ stats)
+{
+    const int wid = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wid >= ntiles) return;
+    const int ti = wid / tiles_x, tj = wid - ti * tiles_x;
+    const int col = lane & 31, rsub = lane >> 5;
+    const int j = tj * P2E_TW + col;
+    const bool jin = j < a.W;
+    const float2 ct = a.col_trig[jin ? j : a.W - 1];
+    int cnt = 0, maxch = 0;
+    for (int n = 0; n < a.tab.N; ++n) {
+        int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
+#pragma unroll
+        for (int k = 0; k < P2E_NPX; ++k) {
+            const int i = ti * P2E_TH + rsub + 2 * k;
+            const bool iin = i < a.H;
+            const float2 rt = a.row_trig[iin ? i : a.H - 1];
+            Taps t;
+            p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);
+            if (jin && iin && wsum > 0.0f) {
+                xmin = min(xmin, t.x0); xmax = max(xmax, t.x1); ymin = min(ymin, t.y0); ymax = max(ymax, t.y1);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            xmin = min(xmin, __shfl_xor(xmin, o)); xmax = max(xmax, __shfl_xor(xmax, o));
+            ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        }
+        if (xmax < 0) continue;                                   // wave-uniform: patch n covers no pixel of this tile
+        const int xa = xmin / epc * epc;
+        const int bw4 = (xmax / epc * epc + epc - xa) / epc, bh = ymax - ymin + 1;
+        const bool fits = bw4 < 1024 && bh < 1024 && xa < 65536 && ymin < 65536 && bw4 * bh <= P2E_MAX_CHUNKS;
+        maxch = max(maxch, fits ? bw4 * bh : P2E_MAX_CHUNKS + 1);
+        if (lane == 0 && cnt < P2E_MAXC && fits)
+            ent[(size_t)wid * P2E_MAXC + cnt] = make_uint2((unsigned)n | ((unsigned)bw4 << 6) | ((unsigned)bh << 16),
+                                                           (unsigned)xa | ((unsigned)ymin << 16));
+        ++cnt;
+    }
+    if (lane == 0) {
+        for (int c = cnt; c < P2E_MAXC; ++c) ent[(size_t)wid * P2E_MAXC + c] = make_uint2(0u, 0u);
+        if (cnt <= P2E_MAXC) ent[(size_t)wid * P2E_MAXC].x |= (unsigned)cnt << 26;
+        atomicMax(&stats[0], maxch); atomicMax(&stats[1], cnt);
+    }
+}
+
+// column origin of a tap pair: the box origin, shifted so that an x1 == x0 tap (right patch edge) becomes the pair's second element
+__device__ __forceinline__ int xa_adj(int x0, int x1, int xa) { return xa + 1 - (x1 - x0); }
+
+template <typename T> struct LdsPair;
+template <> struct LdsPair<float> {
+    static __device__ __forceinline__ void ld(const unsigned char* b, int o, float& x, float& y)
+    { const float* p = reinterpret_cast<const float*>(b) + o; x = p[0]; y = p[1]; }              // one ds_read2_b32
+};
+template <> struct LdsPair<__half> {
+    static __device__ __forceinline__ void ld(const unsigned char* b, int o, float& x, float& y)
+    { const __half* p = reinterpret_cast<const __half*>(b) + o; x = __half2float(p[0]); y = __half2float(p[1]); }
+};
+
+typedef __amdgpu_buffer_rsrc_t p2e_rsrc_t;
+typedef __attribute__((address_space(3))) void* p2e_lptr_t;
+__device__ __forceinline__ p2e_rsrc_t p2e_make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+// one LDS-DMA instruction: lane l's 16 bytes at buffer offset voff + soff (soff wave-uniform) land at lds + 16 l; an offset
+// outside the buffer deposits zeros without touching memory (used for the padding lanes of a box's last piece).
+// (A plain function: the host pass does not accept this builtin inside a kernel template's body.)
+__device__ __forceinline__ void p2e_dma16(p2e_rsrc_t rs, unsigned char* lds, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (p2e_lptr_t)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void p2e_wait_vm()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ONE WAVE (= one 64-thread block) per (ERP tile, group of PL planes); nothing in here synchronises with another wave.  The
+// covering patches of the tile are walked one after the other; per patch: (1) the first NB boxes are put in flight, (2) the tap
+// geometry of my NPX pixels is evaluated while they travel, (3) the PL stages run.  A stage = (patch, plane p): the box of the
+// patch in plane p, NJ = ceil(chunks / 64) DMA pieces of 1 KiB, NB ring slots (stages in flight; PL % NB == 0 so that a stage's
+// slot is a compile-time constant).  The stage loop is instantiated per NJ (1..8), which makes every s_waitcnt count and every
+// DMA piece loop a compile-time constant: waiting for stage p leaves min(NB-1, PL-1-p) later stages = that many x NJ pieces in
+// flight.  The tile is small (4 x 32 pixels, 2 per lane) so that a launch of BASELINE size still has >= 16 waves per CU to
+// hide each other's latencies: with one big tile per wave the launch is a handful of long dependent instruction chains per SIMD
+// (measured: 8 x 32 tiles, 24 us at B = 8 whatever the ring depth).
+template <typename T, int PL, bool CONF, int NB>
+__global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_y,
+                                                        int slot_chunks, unsigned tensor_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char p2e_smem[];        // the ONLY LDS object of this kernel
+    static_assert(PL % NB == 0 && NB >= 1, "slot index must be static");
+    constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = P2E_NPX;
+    const int lane = threadIdx.x;
+    int ti, tj;
+    if (!omni_xcd_rows(blockIdx.x, tiles_y, tiles_x, ti, tj)) return;               // (block-uniform)
+    const int wid = ti * tiles_x + tj;
+    const int col = lane & 31, rsub = lane >> 5;
+    const int j = tj * P2E_TW + col;
+    const bool jin = j < a.W;
+    const int p_begin = (int)blockIdx.y * PL;
+    const unsigned slot_bytes = (unsigned)slot_chunks * 16u * (unsigned)M;
+    unsigned char* const ring = p2e_smem;
+    const p2e_rsrc_t rs1 = p2e_make_rsrc(a.pers, tensor_bytes);
+    const p2e_rsrc_t rs2 = p2e_make_rsrc(CONF ? a.pers2 : a.pers, tensor_bytes);
+    const unsigned sYb = (unsigned)a.sY * (unsigned)sizeof(T), sNb = (unsigned)a.sN * (unsigned)sizeof(T);
+
+    // ---- the trig of my pixels (vector loads) and the tile's patch list (wave-uniform address: scalar loads)
+    const float2 ct = a.col_trig[jin ? j : a.W - 1];
+    float2 rt[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) rt[k] = a.row_trig[min(ti * P2E_TH + rsub + 2 * k, a.H - 1)];
+    const uint2* __restrict__ te = tiles + (size_t)wid * P2E_MAXC;
+    const int ncand = (int)(te[0].x >> 26);
+    unsigned poff_l;                                               // lane p: byte offset of plane p_begin + p (< 2^31, host-checked)
+    {
+        const int p = p_begin + min(lane, PL - 1);
+        const unsigned e = CONF ? (unsigned)p * (unsigned)a.sB : (unsigned)(p / a.C) * (unsigned)a.sB + (unsigned)(p % a.C) * (unsigned)a.sC;
+        poff_l = e * (unsigned)sizeof(T);
+    }
+    // all ordinary vector loads are consumed HERE, before the first LDS-DMA is issued (a later first use would make the compiler
+    // drain the DMA queue with vmcnt(0))
+    asm volatile("" ::"v"(ct.x), "v"(ct.y));
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) asm volatile("" ::"v"(rt[k].x), "v"(rt[k].y));
+
+    float acc[PL][NPX], acc2[CONF ? PL : 1][NPX], l1[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        l1[k] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < PL; ++p) { acc[p][k] = 0.0f; if (CONF) acc2[p][k] = 0.0f; }
+    }
+
+    for (int c = 0; c < ncand; ++c) {
+        const uint2 e = te[c];
+        const unsigned e0 = e.x, e1 = e.y;
+        const int n = e0 & 63, bw4 = (e0 >> 6) & 1023, xa = e1 & 0xffff, ymin = e1 >> 16;
+        const int nchunk = bw4 * (int)((e0 >> 16) & 1023), njj = (nchunk + 63) >> 6;
+        const unsigned base = (unsigned)n * sNb + (unsigned)ymin * sYb + (unsigned)xa * (unsigned)sizeof(T);
+        unsigned g[P2E_NJMAX];                                      // byte offset of my chunk of piece q, from the box origin
+        // ---- (1) fill the ring: stages 0..NB-1
+        auto prologue = [&]<int NJ>(std::integral_constant<int, NJ>) {
+            const float rbw = __builtin_amdgcn_rcpf((float)bw4);
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                const int qc = q * 64 + lane;
+                const int rr = (int)(((float)qc + 0.5f) * rbw);                        // qc / bw4, exact for qc, bw4 <= 1024
+                g[q] = qc < nchunk ? (unsigned)rr * sYb + (unsigned)(qc - rr * bw4) * 16u : 0x80000000u;   // past the end: zeros
+            }
+            if (OMNI_DBG(a, 4)) return;
+#pragma unroll
+            for (int d = 0; d < NB; ++d) {
+                const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)poff_l, d) + base;
+                unsigned char* dst = ring + (unsigned)d * slot_bytes;
+#pragma unroll
+                for (int q = 0; q < NJ; ++q) {
+                    p2e_dma16(rs1, dst + q * 1024, g[q], so);
+                    if (CONF) p2e_dma16(rs2, dst + (unsigned)slot_chunks * 16u + q * 1024, g[q], so);
+                }
+            }
+        };
+        switch (njj) {
+        case 1: prologue(std::integral_constant<int, 1>()); break;
+        case 2: prologue(std::integral_constant<int, 2>()); break;
+        case 3: prologue(std::integral_constant<int, 3>()); break;
+        case 4: prologue(std::integral_constant<int, 4>()); break;
+        case 5: prologue(std::integral_constant<int, 5>()); break;
+        case 6: prologue(std::integral_constant<int, 6>()); break;
+        case 7: prologue(std::integral_constant<int, 7>()); break;
+        default: prologue(std::integral_constant<int, 8>()); break;
+        }
+        // ---- (2) taps of patch n for my pixels, as LDS element offsets inside the box (the DMA latency overlaps this)
+        const int pitch = bw4 * EPC;
+        int r0[NPX], r1[NPX];
+        float wa[NPX], wb[NPX], wc[NPX], wd[NPX];
+        float cd, sd;
+        p2e_lon(a, n, ct.x, ct.y, cd, sd);
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            Taps t;
+            if (OMNI_DBG(a, 1)) { t.x0 = xa + 1; t.x1 = xa + 2; t.y0 = ymin; t.y1 = ymin; t.wa = t.wb = t.wc = t.wd = 0.25f * rt[k].x; }
+            else p2e_taps_cs(a, n, rt[k].x, rt[k].y, cd, sd, t);
+            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);           // all >= 0 after the threshold
+            l1[k] += wsum;
+            // the pair (x0, x0+1) of both tap rows; at the right patch edge (x1 == x0: wa == wb == 0, see p2e_taps_cs) the pair is
+            // moved one column left so that its SECOND element is the x1 tap.  Pixels the patch does not cover have all weights 0
+            // and read the box origin.
+            const int xo = t.x0 - xa_adj(t.x0, t.x1, xa);
+            const bool used = wsum > 0.0f;
+            r0[k] = used ? (t.y0 - ymin) * pitch + xo : 0;
+            r1[k] = used ? (t.y1 - ymin) * pitch + xo : 0;
+            wa[k] = t.wa; wb[k] = t.wb; wc[k] = t.wc; wd[k] = t.wd;
+        }
+        // ---- (3) the PL stages, instantiated on the number of DMA pieces per box
+        auto stages = [&]<int NJ>(std::integral_constant<int, NJ>) {
+            auto stage = [&]<int P>(std::integral_constant<int, P>) {
+                constexpr int SLOT = P % NB;
+                constexpr int K1 = (NB - 1 < PL - 1 - P) ? NB - 1 : PL - 1 - P;
+                p2e_wait_vm<K1 * NJ * M>();
+                const unsigned char* box = ring + (unsigned)SLOT * slot_bytes;
+#pragma unroll
+                for (int k = 0; k < NPX; ++k) {
+                    if (OMNI_DBG(a, 2)) { acc[P][k] += wa[k] * (float)P; continue; }
+                    float ax, ay, bx, by;
+                    LdsPair<T>::ld(box, r0[k], ax, ay);
+                    LdsPair<T>::ld(box, r1[k], bx, by);
+                    // taps (y0,x0) (y1,x0) (y0,x1) (y1,x1) in the gather kernel's order of operations
+                    acc[P][k] += fmaf(by, wd[k], fmaf(ay, wc[k], fmaf(bx, wb[k], ax * wa[k])));
+                    if (CONF) {
+                        const unsigned char* box2 = box + (unsigned)slot_chunks * 16u;
+                        LdsPair<T>::ld(box2, r0[k], ax, ay);
+                        LdsPair<T>::ld(box2, r1[k], bx, by);
+                        acc2[P][k] += fmaf(by, wd[k], fmaf(ay, wc[k], fmaf(bx, wb[k], ax * wa[k])));
+                    }
+                }
+                if constexpr (P + NB < PL) if (!OMNI_DBG(a, 4)) {   // refill the slot just read (its ds_reads must have returned first)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)poff_l, P + NB) + base;
+                    unsigned char* dst = ring + (unsigned)SLOT * slot_bytes;
+#pragma unroll
+                    for (int q = 0; q < NJ; ++q) {
+                        p2e_dma16(rs1, dst + q * 1024, g[q], so);
+                        if (CONF) p2e_dma16(rs2, dst + (unsigned)slot_chunks * 16u + q * 1024, g[q], so);
+                    }
+                }
+            };
+            [&]<int... P>(std::integer_sequence<int, P...>) { (stage(std::integral_constant<int, P>()), ...); }(std::make_integer_sequence<int, PL>());
+        };
+        switch (njj) {
+        case 1: stages(std::integral_constant<int, 1>()); break;
+        case 2: stages(std::integral_constant<int, 2>()); break;
+        case 3: stages(std::integral_constant<int, 3>()); break;
+        case 4: stages(std::integral_constant<int, 4>()); break;
+        case 5: stages(std::integral_constant<int, 5>()); break;
+        case 6: stages(std::integral_constant<int, 6>()); break;
+        case 7: stages(std::integral_constant<int, 7>()); break;
+        default: stages(std::integral_constant<int, 8>()); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the ring is a DMA target again for the next patch
+    }
+    // ---- normalise and store (pers2equi_v3.py:192-196; K11: spherical_model.py:310-311)
+    const size_t erp_plane = (size_t)a.H * a.W;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int i = ti * P2E_TH + rsub + 2 * k;
+        if (!(jin && i < a.H)) continue;
+        if (OMNI_DBG(a, 8) && l1[k] != -1.0f) continue;
+        const float rden = 1.0f / fmaxf(l1[k], 1e-12f);
+        const size_t pix = (size_t)i * a.W + j;
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            const size_t o = (size_t)(p_begin + p) * erp_plane + pix;
+            if (CONF) {
+                const float pr = acc[p][k] * rden, cf = acc2[p][k] * rden;
+                const float z = (cf <= 1e-8f) ? 1.0f : 0.0f;
+                reinterpret_cast<float*>(a.erp)[o] = pr / (cf + 1e-8f * z);
+            } else {
+                Store<T>::st(reinterpret_cast<T*>(a.erp) + o, acc[p][k] * rden);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ backward
 // g_pers[b,c,y,x,n] = sum over the ERP pixels (i,j) whose tap of patch n is (y,x) of w~ * g_erp[b,c,i,j], w~ the thresholded,
 // L1-normalised weights of the forward (the operator is linear in the patches; the weights do not depend on them).
@@ -291,6 +605,10 @@ int fill_args(P2EArgs& a, const omni_geometry* g, const void* pers, const void* 
     a.ky = (float)(1.0 / ((double)(g->fov_h / 180.0f) * (double)PI2f));
     a.half_h = 0.5f * (float)g->ph; a.half_w = 0.5f * (float)g->pw;
     a.tab = g->p2e;
+    a.dbg = 0;
+#ifdef OMNI_DEBUG_BUILD
+    a.dbg = omni_debug_bits("OMNI_P2E_DBG");
+#endif
     return OMNI_OK;
 }
 
@@ -303,6 +621,52 @@ void launch_p2e_pl(const P2EArgs& a, int planes, int rows4, int nblocks, hipStre
     else                  hipLaunchKernelGGL((p2e_kernel<T, 8, CONF, XS1>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
 }
 
+// ---- LDS path: launch geometry.  One wave per (tile, group of PL planes); ring = NB slots of the geometry's largest box (x2
+// for the fused confidence blend: both tensors' boxes travel together).  NB: 4 while the ring stays <= 16 KiB per wave (>= 10
+// waves per CU by LDS), else 2; option "p2e_nbuf" overrides (tuning).
+template <typename T, int PL, bool CONF, int NB>
+int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
+{
+    const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
+    const int slot_chunks = (tt.max_chunks + 63) / 64 * 64;
+    const size_t lds = (size_t)NB * slot_chunks * 16 * (CONF ? 2 : 1);
+    hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NB>), dim3(omni_xcd_rows_grid(g->p2e_ty, g->p2e_tx), planes / PL), dim3(64), lds, stream, a,
+                       (const uint2*)tt.ent, g->p2e_tx, g->p2e_ty, slot_chunks, (unsigned)tensor_bytes);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+template <typename T, int PL, bool CONF>
+int launch_p2e_lds_pl(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
+{
+    const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
+    const int slot_bytes = (tt.max_chunks + 63) / 64 * 64 * 16 * (CONF ? 2 : 1);
+    int nb = omni_options().p2e_nbuf;
+    if (nb <= 0) nb = 4 * slot_bytes <= 10240 ? 4 : 2;                // ring <= 10 KiB per wave: 16 waves per CU by LDS
+    if constexpr (PL >= 4) {
+        if (nb >= 4) return launch_p2e_lds_nb<T, PL, CONF, 4>(a, g, planes, tensor_bytes, stream);
+        if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, planes, tensor_bytes, stream);
+        return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
+    } else if constexpr (PL == 2) {
+        if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, planes, tensor_bytes, stream);
+        return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
+    } else {
+        return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
+    }
+}
+
+template <typename T, bool CONF>
+int launch_p2e_lds(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
+{
+    // planes per wave: the largest of 8, 4, 2, 1 that divides the plane count (the tap geometry is evaluated once per wave and
+    // patch and amortised over them); the groups go to blockIdx.y
+    const int cap = omni_options().p2e_planes > 0 ? omni_options().p2e_planes : (CONF ? 4 : 8);   // (CONF, 8 planes: 2 x 16 accumulators spill at 128 VGPRs)
+    if (planes % 8 == 0 && cap >= 8) return launch_p2e_lds_pl<T, 8, CONF>(a, g, planes, tensor_bytes, stream);
+    if (planes % 4 == 0 && cap >= 4) return launch_p2e_lds_pl<T, 4, CONF>(a, g, planes, tensor_bytes, stream);
+    if (planes % 2 == 0 && cap >= 2) return launch_p2e_lds_pl<T, 2, CONF>(a, g, planes, tensor_bytes, stream);
+    return launch_p2e_lds_pl<T, 1, CONF>(a, g, planes, tensor_bytes, stream);
+}
+
 template <typename T, bool CONF>
 int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void* erp, int B, int C,
                int layout, hipStream_t stream)
@@ -312,9 +676,17 @@ int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void
     if (rc != OMNI_OK) return rc;
     if ((long long)g->N * C * g->ph * g->pw >= (1ll << 31))
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_pers2equi: one batch item of the patch tensor must hold < 2^31 elements");
-    const int rows4 = (g->H + 3) / 4;
-    const int nblocks = rows4 * g->ntx;
     const int planes = CONF ? B : B * C;
+    // LDS-staged path: planar patches whose rows are whole 16-byte chunks, boxes that fit a slot, 32-bit element offsets
+    const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const bool aligned = ((uintptr_t)pers % 16 == 0) && (!pers2 || (uintptr_t)pers2 % 16 == 0) &&
+                         g->pw % EPC == 0 && (g->ph * g->pw) % EPC == 0;
+    const long long tensor_bytes = (long long)B * g->N * C * g->ph * g->pw * (long long)sizeof(T);
+    if (a.sX == 1 && tt.ok && aligned && !omni_options().p2e_gather && tensor_bytes < (1ll << 31))   // 32-bit buffer offsets
+        return launch_p2e_lds<T, CONF>(a, g, planes, (size_t)tensor_bytes, stream);
+    const int rows4 = (g->H + 3) / 4;
+    const int nblocks = omni_xcd_rows_grid(rows4, g->ntx);
     if (a.sX == 1 && g->pw >= 2) launch_p2e_pl<T, CONF, true>(a, planes, rows4, nblocks, stream);
     else                         launch_p2e_pl<T, CONF, false>(a, planes, rows4, nblocks, stream);
     OMNI_HIP(hipGetLastError());
@@ -340,6 +712,36 @@ int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream)
     OMNI_HIP(hipGetLastError());
     // one-time setup: make the table visible to every stream that may use this handle later
     OMNI_HIP(hipStreamSynchronize(stream));
+    return OMNI_OK;
+}
+
+// Per-tile box tables of the LDS path (one per element size: the 16-byte chunk alignment differs).  One-time setup.
+int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
+{
+    P2EArgs a;
+    int rc = fill_args(a, g, nullptr, nullptr, nullptr, 0, 1, OMNI_LAYOUT_BNCHW);
+    if (rc != OMNI_OK) return rc;
+    g->p2e_tx = (g->W + P2E_TW - 1) / P2E_TW; g->p2e_ty = (g->H + P2E_TH - 1) / P2E_TH;
+    const long long ntiles = (long long)g->p2e_tx * g->p2e_ty;
+    if (ntiles >= (1ll << 28)) return OMNI_OK;                     // absurd sizes: gather path only
+    int* dstats = nullptr;
+    OMNI_HIP(hipMalloc((void**)&dstats, 2 * sizeof(int)));
+    for (int e = 0; e < 2; ++e) {
+        auto& tt = g->p2e_tiles[e];
+        const int epc = e ? 8 : 4;
+        if (hipMalloc((void**)&tt.ent, sizeof(uint2) * (size_t)ntiles * P2E_MAXC) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: out of memory"); }
+        if (hipMemsetAsync(dstats, 0, 2 * sizeof(int), stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: memset"); }
+        hipLaunchKernelGGL(p2e_tiles_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, a, tt.ent, g->p2e_tx, (int)ntiles, epc, dstats);
+        int hs[2] = {0, 0};
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, dstats, sizeof(hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: kernel failed"); }
+        tt.max_chunks = hs[0]; tt.max_cand = hs[1];
+        tt.ok = (hs[0] <= P2E_MAX_CHUNKS && hs[1] <= P2E_MAXC && g->pw % epc == 0) ? 1 : 0;
+        if (omni_options().e2p_verbose)
+            fprintf(stderr, "[omni] pers2equi %dx%d <- %d patches %dx%d, %d-byte elements: largest tap box %d chunks, <= %d patches per %dx%d tile -> %s\n",
+                    g->H, g->W, g->N, g->ph, g->pw, 16 / epc, hs[0], hs[1], P2E_TH, P2E_TW, tt.ok ? "LDS path" : "gather path");
+    }
+    (void)hipFree(dstats);
     return OMNI_OK;
 }
 

@@ -410,11 +410,11 @@ def test_sh_range_guard_and_large_magnitudes():
     assert b[5] == 1.0 and b[6] == -2.5 and abs(b[7].item() - 6e4) < 0.02
     assert lib.omni_sh_overflow(ctypes.byref(flag), 1) == 0 and flag.value == 1   # raised, then cleared by reset
     assert lib.omni_sh_overflow(ctypes.byref(flag), 0) == 0 and flag.value == 0
-    # conv on activations ~ 2e4 (outputs ~ 3e4): relative error stays at the 1e-6 level
+    # conv on activations up to ~4.5e4 (sigma 1e4; outputs ~ 1.5e4): relative error stays at the 1e-6 level
     from omnifusion_amd.model._engine import split_weights_f16x3
     g = torch.Generator().manual_seed(5)
     M, H, W, C, Co = 2, 16, 16, 64, 64
-    x1 = torch.randn(M, H, W, C, generator=g) * 2e4
+    x1 = (torch.randn(M, H, W, C, generator=g) * 1e4).clamp(-6e4, 6e4)
     w = torch.randn(Co, C, 3, 3, generator=g) / np.sqrt(C * 9)
     ref = F.conv2d(x1.permute(0, 3, 1, 2).double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
     wt = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()

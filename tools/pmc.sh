@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
            "FETCH_SIZE" "WRITE_SIZE" "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o p$i -- python $GRAFT_REPO_ROOT/tools/kbench.py "$@" > $out/p$i.log 2>&1
+  timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o p$i -- python $GRAFT_REPO_ROOT/tools/kbench.py "$@" > $out/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
@@ -23,7 +23,7 @@ for f in glob.glob("$out/p*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "e2p" in k or "p2e_kernel" in k or "copy" in k.lower() or "elementwise" in k:
+    if "e2p" in k or "p2e" in k or "copy" in k.lower() or "elementwise" in k:
         print(k)
         for c, v in sorted(d.items()):
             print(f"   {c:40s} n={len(v):3d} mean={sum(v)/len(v):.4g}")

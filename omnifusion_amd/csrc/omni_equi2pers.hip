@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "omni_internal.h"
 
 namespace {
@@ -129,6 +131,14 @@ template <> struct Pair<__half> {
       x = __low2float(h); y = __high2float(h); }
 };
 
+// ATen's bilinear sum nw*w00 + ne*w01 + sw*w10 + se*w11, associated COLUMN-wise — (v00 w00 + v10 w10) + (v01 w01 + v11 w11) — so that a tap
+// pair (x0, x0+1) read as one 8-byte value goes through two packed operations (v_pk_mul_f32, v_pk_fma_f32) and one add without
+// any register shuffling.  EVERY equi2pers kernel (gather, LDS box, reference layout, fallback) uses this one function: same bits.
+__device__ __forceinline__ float e2p_blend(float v00, float v01, float v10, float v11, float w00, float w01, float w10, float w11)
+{
+    return fmaf(v10, w10, v00 * w00) + fmaf(v11, w11, v01 * w01);
+}
+
 template <typename T, bool PAIR>
 __device__ __forceinline__ float e2p_fetch(const T* __restrict__ img, const Tap& p)
 {
@@ -142,7 +152,7 @@ __device__ __forceinline__ float e2p_fetch(const T* __restrict__ img, const Tap&
         v00 = Store<T>::ld(img + p.r0); v01 = Store<T>::ld(img + p.r0 + p.sel);
         v10 = Store<T>::ld(img + p.r1); v11 = Store<T>::ld(img + p.r1 + p.sel);
     }
-    return fmaf(v11, p.w11, fmaf(v10, p.w10, fmaf(v01, p.w01, v00 * p.w00)));
+    return e2p_blend(v00, v01, v10, v11, p.w00, p.w01, p.w10, p.w11);
 }
 
 // ------------------------------------------------------------------ planar output [B,N,C,ph,pw]
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
             for (int k = 0; k < SPT; ++k) {
                 const float a0 = cur[r0[k]], a1 = cur[r0[k] + 1];              // one ds_read2_b32 per tap row
                 const float b0 = cur[r1[k]], b1 = cur[r1[k] + 1];
-                r[k] = fmaf(s1[k] ? b1 : b0, w11[k], fmaf(b0, w10[k], fmaf(s1[k] ? a1 : a0, w01[k], a0 * w00[k])));
+                r[k] = e2p_blend(a0, s1[k] ? a1 : a0, b0, s1[k] ? b1 : b0, w00[k], w01[k], w10[k], w11[k]);
             }
 #pragma unroll
             for (int k = 0; k < SPT; ++k) dst[k * ostep] = r[k];
@@ -478,10 +488,272 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
             for (int k = 0; k < SPT; ++k) {
                 const int g0 = y0[k] * W + x0[k], g1 = y1[k] * W + x0[k];
                 const float v00 = img[g0], v01 = img[g0 + s1[k]], v10 = img[g1], v11 = img[g1 + s1[k]];
-                const float r = fmaf(v11, w11[k], fmaf(v10, w10[k], fmaf(v01, w01[k], v00 * w00[k])));
+                const float r = e2p_blend(v00, v01, v10, v11, w00[k], w01[k], w10[k], w11[k]);
                 if (ok[k]) dst[k * ostep] = r;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------ planar output, one wave per small sample tile (default)
+// e2p_lds_kernel above synchronises a 256-thread block once per image plane and keeps two boxes in flight; measured 46 us for the
+// 164 MB of BASELINE cfg 4 (3.6 TB/s), its waves parked at the barrier / the DMA wait most of the time.  Here ONE WAVE owns a
+// tile of 8 x 32 samples (4 horizontally adjacent ones per lane: one 16-byte store per lane and plane) and streams the B*C image planes through a ring of NB LDS slots: per plane the bounding box of the tile's taps on
+// the ERP arrives by LDS-DMA (buffer_load ... lds, 1 KiB pieces), the wave waits with a COUNTED s_waitcnt for exactly the
+// pieces of the stage it is about to read (the NB-1 younger stages and the stores stay in flight), takes the taps from LDS and
+// stores 4 samples per lane.  No barrier, no block-level reduction: the box of every tile is a constant of the geometry (table
+// built once per handle from the same sampling coordinates).  The stage loop is instantiated per NJ = pieces per box, so every
+// wait count and piece loop is a compile-time constant.  Tiles whose box exceeds the slot (the pole inside or next to the
+// tile) are listed per geometry and handled by extra blocks of the same launch with direct gathers, one per (tile, batch item).
+constexpr int E2B_NPX = 4;                      // samples per lane
+constexpr int E2B_NJMAX = 8;                    // 1-KiB DMA pieces per box at most
+
+typedef __amdgpu_buffer_rsrc_t e2b_rsrc_t;
+typedef __attribute__((address_space(3))) void* e2b_lptr_t;
+__device__ __forceinline__ void e2b_dma16(e2b_rsrc_t rs, unsigned char* lds, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (e2b_lptr_t)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void e2b_wait_vm()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <typename T> struct E2BPair;
+template <> struct E2BPair<float> {
+    static __device__ __forceinline__ void ld(const unsigned char* b, int o, float& x, float& y)
+    { const float* p = reinterpret_cast<const float*>(b) + o; x = p[0]; y = p[1]; }
+};
+template <> struct E2BPair<__half> {
+    static __device__ __forceinline__ void ld(const unsigned char* b, int o, float& x, float& y)
+    { const __half* p = reinterpret_cast<const __half*>(b) + o; x = __half2float(p[0]); y = __half2float(p[1]); }
+};
+
+// clamped sampling coordinate of sample (n, h, w): from the per-geometry table, or evaluated on the fly (same function, same bits)
+__device__ __forceinline__ void e2b_xy(const E2PArgs& a, int n, int h, int w, float& ix, float& iy)
+{
+    if (a.ixy) { const float2 c = a.ixy[((size_t)n * a.ph + h) * a.pw + w]; ix = c.x; iy = c.y; }
+    else e2p_sample_xy(a, n, h, w, ix, iy);
+}
+
+// table entry of one tile: x = bw4 | bh << 12 | fits << 31 (bw4 = 16-byte chunks per box row, bh = box rows),
+//                          y = xs4 | ymin << 16 (first box column, chunk-aligned, the box wraps at the seam; first box row)
+// lane -> samples: the tile is E2B_TH = 8 rows x E2B_TW = 32 columns; lane l owns the 4 horizontally adjacent samples
+// (row l / 8, columns 4 (l % 8) .. +3): ONE 16-byte (fp16: 8-byte) store per lane and plane, 128-byte (64-byte) row segments
+constexpr int E2B_TH = 8, E2B_TW = 32;
+
+__global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __restrict__ ent, int tiles_x, int tiles_pp, int ntiles, int epc,
+                                                        int cap_chunks, int* __restrict__ stats)
+{
+    const int wid = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wid >= ntiles) return;
+    const int n = wid / tiles_pp, t = wid - n * tiles_pp;
+    const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
+    const int h = min(th0 + (lane >> 3), a.ph - 1);
+    const int W = a.W, H = a.H, half = W >> 1;
+    int x0[E2B_NPX], ymin = 0x7fffffff, ymax = -1;
+#pragma unroll
+    for (int k = 0; k < E2B_NPX; ++k) {
+        const int w = min(tw0 + 4 * (lane & 7) + k, a.pw - 1);
+        float ix, iy;
+        e2b_xy(a, n, h, w, ix, iy);
+        const int y0 = (int)floorf(iy);                            // (NaN -> 0: ATen clips the NaN row coordinate of quirk q4 to 0)
+        x0[k] = (int)floorf(ix);
+        ymin = min(ymin, y0); ymax = max(ymax, min(y0 + 1, H - 1));
+    }
+    const int xc = __shfl(x0[0], 0);
+    int dmin = 0x7fffffff, dmax = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < E2B_NPX; ++k) {
+        int d = x0[k] - xc;
+        if (d >= half) d -= W;
+        if (d < -half) d += W;
+        dmin = min(dmin, d); dmax = max(dmax, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        dmin = min(dmin, __shfl_xor(dmin, o)); dmax = max(dmax, __shfl_xor(dmax, o));
+    }
+    int xs = xc + dmin;
+    if (xs < 0) xs += W;
+    if (xs >= W) xs -= W;
+    const int xs4 = xs / epc * epc, shift = xs - xs4;
+    const int bw4 = (dmax - dmin + 2 + shift + epc - 1) / epc;     // columns x0 .. x0+1 of every sample, whole 16-byte chunks
+    const int bh = ymax - ymin + 1;
+    const bool fits = (W % epc == 0) && bw4 * epc <= W && bw4 < 4096 && bh < 4096 && bw4 * bh <= cap_chunks;
+    if (lane == 0) {
+        ent[wid] = make_uint2((unsigned)(bw4 & 4095) | ((unsigned)(bh & 4095) << 12) | (fits ? 0x80000000u : 0u), (unsigned)xs4 | ((unsigned)ymin << 16));
+        if (fits) atomicMax(&stats[0], bw4 * bh);
+        else stats[2 + atomicAdd(&stats[1], 1)] = wid;             // fallback list (order irrelevant)
+    }
+}
+
+// NPX results of one lane -> NPX adjacent elements, one store
+template <typename T> struct E2BStore4;
+template <> struct E2BStore4<float> {
+    static __device__ __forceinline__ void st(float* p, const float (&r)[4]) { *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]); }
+};
+template <> struct E2BStore4<__half> {
+    static __device__ __forceinline__ void st(__half* p, const float (&r)[4])
+    { __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]); uint2 v; v.x = *reinterpret_cast<unsigned*>(&lo); v.y = *reinterpret_cast<unsigned*>(&hi); *reinterpret_cast<uint2*>(p) = v; }
+};
+
+template <typename T, int NB>
+__global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_pp,
+                                                        const int* __restrict__ fb, int nfb_blocks, const int* __restrict__ order, int lds_start,
+                                                        int slot_chunks, unsigned tensor_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char e2b_smem[];        // the ONLY LDS object of this kernel
+    constexpr int EPC = 16 / (int)sizeof(T), NPX = E2B_NPX;
+    const int lane = threadIdx.x;
+    // grid: [0, nfb_blocks) one block per (listed tile, batch item), direct gathers — FIRST, so that these latency-bound stragglers
+    // run under the streaming blocks instead of after them; [lds_start, ..) the LDS tiles in `order`: block lds_start + k runs on
+    // XCD k % 8 (lds_start is a multiple of 8) and order[k] is a tile of ERP longitude sector k % 8, so that the tiles of ALL
+    // patches that read one region of the panorama share one L2 (an ERP pixel is sampled by 2.1 patches on average)
+    const bool fb_block = (int)blockIdx.x < nfb_blocks;
+    int wid, fb_b = 0;
+    if (fb_block) { wid = fb[blockIdx.x / a.B]; fb_b = blockIdx.x % a.B; }
+    else {
+        if ((int)blockIdx.x < lds_start) return;                   // alignment padding
+        wid = order[(int)blockIdx.x - lds_start];
+        if (wid < 0) return;                                       // sector padding
+    }
+    const uint2 e = tiles[wid];                                    // wave-uniform address: scalar load
+    const int n = wid / tiles_pp, t = wid - n * tiles_pp;
+    const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
+    const int W = a.W, H = a.H;
+    const int w = tw0 + 4 * (lane & 7), hb = th0 + (lane >> 3);
+    const int xs4 = (int)(e.y & 0xffff), ymin = (int)(e.y >> 16), bw4 = (int)(e.x & 4095), bh = (int)((e.x >> 12) & 4095);
+    const int pitch = bw4 * EPC;
+
+    // ---- taps of my NPX samples: LDS element offsets inside the box + ATen's four weights
+    int r0[NPX], r1[NPX];
+    float w00[NPX], w01[NPX], w10[NPX], w11[NPX];
+    int gx0[NPX], gy0[NPX], gy1[NPX];                              // (fallback path: absolute taps)
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        float ix, iy;
+        e2b_xy(a, n, hb, w + k, ix, iy);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
+        w00[k] = ey * ex; w01[k] = ey * tx; w10[k] = ty * ex; w11[k] = ty * tx;
+        const int y1 = min(y0 + 1, H - 1);
+        gx0[k] = x0; gy0[k] = y0; gy1[k] = y1;
+        int c0 = x0 - xs4;                                         // column inside the (seam-wrapping) box
+        if (c0 < 0) c0 += W;
+        if (x0 + 1 >= W) {
+            // ix is clamped to W-1: tx == 0, the +1 column is outside the image and its weights (w01, w11) are exactly 0.  Read the
+            // pair (x0-1, x0) instead and move the x0 weights to the pair's SECOND element: e2p_blend then returns
+            // 0 + (v00 w00 + v10 w10) with the same roundings, and nothing outside the image row is read.
+            c0 -= 1;
+            w01[k] = w00[k]; w00[k] = 0.0f; w11[k] = w10[k]; w10[k] = 0.0f;
+        }
+        r0[k] = (y0 - ymin) * pitch + c0;
+        r1[k] = (y1 - ymin) * pitch + c0;
+    }
+    const int plane = a.ph * a.pw;
+    const size_t img_plane = (size_t)H * W;
+    const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
+    T* out = (T*)a.pers + (size_t)n * a.C * plane + (size_t)hb * a.pw + w;
+    const int planes = a.B * a.C;
+
+    if (fb_block) {
+        // ---- direct gathers (same taps, same fma chain) for one batch item of a tile whose box does not fit a slot
+        const T* erp = (const T*)a.erp;
+        T* dstb = out + (size_t)fb_b * out_bstride;
+        for (int c = 0; c < a.C; ++c) {
+            const T* img = erp + ((size_t)fb_b * a.C + c) * img_plane;
+            float r[NPX];
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) {
+                const int sh = (gx0[k] + 1 >= W) ? 1 : 0;          // pair moved one column left (see above)
+                const int g0 = gy0[k] * W + gx0[k] - sh, g1 = gy1[k] * W + gx0[k] - sh;
+                const float v00 = Store<T>::ld(img + g0), v01 = Store<T>::ld(img + g0 + 1);
+                const float v10 = Store<T>::ld(img + g1), v11 = Store<T>::ld(img + g1 + 1);
+                r[k] = e2p_blend(v00, v01, v10, v11, w00[k], w01[k], w10[k], w11[k]);
+            }
+            E2BStore4<T>::st(dstb + (size_t)c * plane, r);
+        }
+        return;
+    }
+    // every ordinary load has been consumed (the taps depend on them): nothing but LDS-DMA pieces and stores below
+    const unsigned slot_bytes = (unsigned)slot_chunks * 16u;
+    const e2b_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.erp), (short)0, (int)tensor_bytes, 0x00020000);
+    const unsigned rowb = (unsigned)W * (unsigned)sizeof(T), planeb = (unsigned)img_plane * (unsigned)sizeof(T);
+    const int nchunk = bw4 * bh, njj = (nchunk + 63) >> 6;
+    const size_t bskip = out_bstride - (size_t)a.C * plane;
+
+    auto run = [&]<int NJ>(std::integral_constant<int, NJ>) {
+        unsigned g[NJ];                                             // byte offset of my chunk of piece q inside an image plane
+        {
+            const float rbw = __builtin_amdgcn_rcpf((float)bw4);
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                const int qc = q * 64 + lane;
+                const int rr = (int)(((float)qc + 0.5f) * rbw);                    // qc / bw4, exact for qc, bw4 <= 4096
+                int gx = xs4 + (qc - rr * bw4) * EPC;
+                if (gx >= W) gx -= W;                                                 // the box wraps at the seam
+                g[q] = qc < nchunk ? (unsigned)(ymin + rr) * rowb + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;   // past the end: zeros
+            }
+        }
+        auto issue = [&](int p, int slot) {
+            if (OMNI_DBG(a, 2)) return;
+            unsigned char* dst = e2b_smem + (unsigned)slot * slot_bytes;
+            const unsigned so = (unsigned)p * planeb;
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) e2b_dma16(rs, dst + q * 1024, g[q], so);
+        };
+        T* dst = out;
+        int cc = 0;
+        auto consume = [&](int slot) {
+            const unsigned char* box = e2b_smem + (unsigned)slot * slot_bytes;
+            float r[NPX];
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) {
+                float a0, a1, b0, b1;
+                E2BPair<T>::ld(box, r0[k], a0, a1);
+                E2BPair<T>::ld(box, r1[k], b0, b1);
+                r[k] = e2p_blend(a0, a1, b0, b1, w00[k], w01[k], w10[k], w11[k]);
+            }
+            if (!OMNI_DBG(a, 1)) E2BStore4<T>::st(dst, r);
+            dst += plane;
+            if (++cc == a.C) { cc = 0; dst += bskip; }
+        };
+        // groups of NB stages (planes % NB == 0, host-checked).  vmcnt counts, per stage s of a group (in-order completion; the ONE
+        // store of a stage counts like a DMA piece):  first group  (NB-1) NJ + s   |  middle  (NB-1)(1 + NJ)
+        //                                             last group   (NB-1) + (NB-1-s) NJ   |  only group  (NB-1-s) NJ + s
+        const int groups = planes / NB;
+#pragma unroll
+        for (int d = 0; d < NB; ++d) issue(d, d);
+        auto group = [&]<int KIND>(std::integral_constant<int, KIND>, int p0) {
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                (([&] {
+                    constexpr int CNT = KIND == 0 ? (NB - 1) * NJ + S : KIND == 1 ? (NB - 1) * (1 + NJ)
+                                      : KIND == 2 ? (NB - 1) + (NB - 1 - S) * NJ : (NB - 1 - S) * NJ + S;
+                    e2b_wait_vm<CNT>();
+                    consume(S);
+                    if (KIND <= 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(p0 + S + NB, S); }
+                }()), ...);
+            }(std::make_integer_sequence<int, NB>());
+        };
+        if (groups == 1) group(std::integral_constant<int, 3>(), 0);
+        else {
+            group(std::integral_constant<int, 0>(), 0);
+            for (int gi = 1; gi + 1 < groups; ++gi) group(std::integral_constant<int, 1>(), gi * NB);
+            group(std::integral_constant<int, 2>(), (groups - 1) * NB);
+        }
+    };
+    switch (njj) {
+    case 1: run(std::integral_constant<int, 1>()); break;
+    case 2: run(std::integral_constant<int, 2>()); break;
+    case 3: run(std::integral_constant<int, 3>()); break;
+    case 4: run(std::integral_constant<int, 4>()); break;
+    case 5: run(std::integral_constant<int, 5>()); break;
+    case 6: run(std::integral_constant<int, 6>()); break;
+    case 7: run(std::integral_constant<int, 7>()); break;
+    default: run(std::integral_constant<int, 8>()); break;
     }
 }
 
@@ -670,7 +942,94 @@ int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream)
     return OMNI_OK;
 }
 
+// Per-tile tap boxes of e2p_box_kernel, one table per element size (tile shape and 16-byte chunk alignment differ).  One-time setup.
+int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
+{
+    E2PArgs a; fill_args(a, g, nullptr, nullptr, 1, 1);
+    int cap_kb = omni_options().e2p_slot_kb;
+    if (cap_kb < 1) cap_kb = 1;
+    if (cap_kb > E2B_NJMAX) cap_kb = E2B_NJMAX;
+    for (int e = 0; e < 2; ++e) {
+        auto& tt = g->e2p_boxes[e];
+        tt.tw = E2B_TW; tt.th = E2B_TH;
+        tt.ok = 0;
+        if (g->pw % tt.tw != 0 || g->ph % tt.th != 0 || g->W < 2) continue;      // whole tiles only (16-byte stores, static store count per stage)
+        tt.tx = g->pw / tt.tw; tt.ty = g->ph / tt.th;
+        const long long ntiles = (long long)g->N * tt.tx * tt.ty;
+        if (ntiles >= (1ll << 24)) continue;
+        const int epc = e ? 8 : 4;
+        int* dstats = nullptr;
+        OMNI_HIP(hipMalloc((void**)&dstats, sizeof(int) * (size_t)(2 + ntiles)));
+        if (hipMalloc((void**)&tt.ent, sizeof(uint2) * (size_t)ntiles) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_e2p_build_boxes: out of memory"); }
+        (void)hipMemsetAsync(dstats, 0, 2 * sizeof(int), stream);
+        const unsigned nb = (unsigned)((ntiles + 3) / 4);
+        hipLaunchKernelGGL(e2b_tiles_kernel, dim3(nb), dim3(256), 0, stream, a, tt.ent, tt.tx, tt.tx * tt.ty, (int)ntiles, epc, cap_kb * 64, dstats);
+        std::vector<int> hs((size_t)(2 + ntiles));
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs.data(), dstats, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_e2p_build_boxes: kernel failed"); }
+        (void)hipFree(dstats);
+        tt.max_chunks = hs[0]; tt.nfb = hs[1];
+        {
+            // LDS-path tiles grouped by the ERP longitude sector (W/8 columns each) of their box centre, one sector per XCD; inside a
+            // sector by latitude (box row), then longitude: tiles that run at the same time read neighbouring boxes
+            std::vector<uint2> he((size_t)ntiles);
+            OMNI_HIP(hipMemcpy(he.data(), tt.ent, sizeof(uint2) * (size_t)ntiles, hipMemcpyDeviceToHost));
+            std::vector<std::vector<std::pair<unsigned, int>>> sec(8);
+            for (int i = 0; i < (int)ntiles; ++i) {
+                if (!(he[i].x >> 31)) continue;
+                const int xs4 = (int)(he[i].y & 0xffff), ymin = (int)(he[i].y >> 16), bw = (int)(he[i].x & 4095) * epc;
+                int xc = xs4 + bw / 2; if (xc >= g->W) xc -= g->W;
+                const int sx = (int)((long long)xc * 8 / g->W) & 7;
+                sec[sx].push_back({((unsigned)(ymin / 8) << 16) | (unsigned)xc, i});
+            }
+            size_t mx = 0;
+            for (auto& v : sec) { std::sort(v.begin(), v.end()); mx = v.size() > mx ? v.size() : mx; }
+            std::vector<int> ord(mx * 8, -1);
+            for (int x = 0; x < 8; ++x) for (size_t i = 0; i < sec[x].size(); ++i) ord[i * 8 + x] = sec[x][i].second;
+            tt.norder = (int)ord.size();
+            if (tt.norder > 0) {
+                OMNI_HIP(hipMalloc((void**)&tt.order, sizeof(int) * ord.size()));
+                OMNI_HIP(hipMemcpy(tt.order, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
+            }
+        }
+        if (tt.nfb > 0) {
+            OMNI_HIP(hipMalloc((void**)&tt.fb, sizeof(int) * (size_t)tt.nfb));
+            OMNI_HIP(hipMemcpy(tt.fb, hs.data() + 2, sizeof(int) * (size_t)tt.nfb, hipMemcpyHostToDevice));
+        }
+        tt.ok = (tt.max_chunks > 0 || tt.nfb > 0) ? 1 : 0;
+        if (omni_options().e2p_verbose)
+            fprintf(stderr, "[omni] equi2pers %dx%d patches on %dx%d, %d-byte elements, %dx%d sample tiles: largest staged tap box %d chunks, "
+                            "%d of %lld tiles take the gather path (box > %d KiB)\n", g->ph, g->pw, g->H, g->W, 16 / epc, tt.th, tt.tw, tt.max_chunks,
+                    tt.nfb, ntiles, cap_kb);
+    }
+    return OMNI_OK;
+}
+
 namespace {
+template <typename T, int NB>
+int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, size_t tensor_bytes, hipStream_t stream)
+{
+    const auto& tt = g->e2p_boxes[sizeof(T) == 2 ? 1 : 0];
+    const int slot_chunks = (tt.max_chunks + 63) / 64 * 64;
+    const int nfb_blocks = tt.nfb * B, lds_start = (nfb_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((e2p_box_kernel<T, NB>), dim3(lds_start + tt.norder), dim3(64), (size_t)NB * slot_chunks * 16, stream, a,
+                       (const uint2*)tt.ent, tt.tx, tt.tx * tt.ty, (const int*)tt.fb, nfb_blocks, (const int*)tt.order, lds_start,
+                       slot_chunks, (unsigned)tensor_bytes);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+template <typename T>
+int launch_e2b(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t tensor_bytes, hipStream_t stream)
+{
+    const int planes = B * C;
+    int nb = omni_options().e2p_nbuf;
+    if (nb <= 0) nb = 2;
+    if (nb >= 4 && planes % 4 == 0) return launch_e2b_nb<T, 4>(a, g, B, tensor_bytes, stream);
+    if (nb >= 2 && planes % 2 == 0) return launch_e2b_nb<T, 2>(a, g, B, tensor_bytes, stream);
+    return launch_e2b_nb<T, 1>(a, g, B, tensor_bytes, stream);
+}
+
 template <typename T>
 int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C, int layout, hipStream_t stream)
 {
@@ -679,6 +1038,10 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
     const bool pair = g->W >= 2;
     if (layout == OMNI_LAYOUT_BNCHW) {
         int spt = 2, unr = 3;
+        const auto& bt = g->e2p_boxes[sizeof(T) == 2 ? 1 : 0];
+        const long long tensor_bytes = (long long)B * C * g->H * g->W * (long long)sizeof(T);
+        if (bt.ok && !omni_options().e2p_gather && tensor_bytes < (1ll << 31) && (uintptr_t)erp % 16 == 0 && (uintptr_t)pers % 16 == 0)
+            return launch_e2b<T>(a, g, B, C, (size_t)tensor_bytes, stream);
         if (sizeof(T) == 4 && !omni_options().e2p_gather && g->W >= 2) {
             const int ts = g->e2p_ts;
             const int tx = (g->pw + ts - 1) / ts, ty = (g->ph + ts - 1) / ts;

@@ -34,9 +34,10 @@ const OptName kOpts[] = {
     {"e2p_verbose", "OMNI_E2P_VERBOSE", &OmniOptions::e2p_verbose, 0},
     {"e2p_bwd_simple", "OMNI_E2P_BWD_SIMPLE", &OmniOptions::e2p_bwd_simple, 0},
     {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
+    {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},
+    {"e2p_slot_kb", "OMNI_E2P_SLOT_KB", &OmniOptions::e2p_slot_kb, 6},
     {"p2e_nbuf", "OMNI_P2E_NBUF", &OmniOptions::p2e_nbuf, 0},
     {"p2e_planes", "OMNI_P2E_PLANES", &OmniOptions::p2e_planes, 0},
-    {"p2e_bpc", "OMNI_P2E_BPC", &OmniOptions::p2e_bpc, 0},
     {"geom_cache_max", "OMNI_GEOM_CACHE_MAX", &OmniOptions::geom_cache_max, 16},
 };
 }  // namespace
@@ -170,6 +171,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     g->row_trig = nullptr; g->col_trig = nullptr; g->cand = nullptr; g->ntx = (W + 63) / 64;
     g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0; g->e2p_ixy = nullptr; g->e2p_ts = 32;
     for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; }
+    for (auto& t : g->e2p_boxes) { t.ent = nullptr; t.fb = nullptr; t.order = nullptr; t.norder = 0; t.nfb = 0; t.max_chunks = 0; t.ok = 0; t.tw = t.th = t.tx = t.ty = 0; }
     g->p2e_tx = g->p2e_ty = 0;
 
     if (H > 0 && W > 0) {
@@ -186,6 +188,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
         int rc = omni_p2e_build_candidates(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_p2e_build_tiles(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_tileflags(g.get(), stream);
+        if (rc == OMNI_OK) rc = omni_e2p_build_boxes(g.get(), stream);
         if (rc != OMNI_OK) { omni_geometry_destroy(g.release()); return rc; }
     }
     *out = g.release();
@@ -199,6 +202,7 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->col_trig) (void)hipFree(g->col_trig);
     if (g->cand) (void)hipFree(g->cand);
     for (auto& t : g->p2e_tiles) if (t.ent) (void)hipFree(t.ent);
+    for (auto& t : g->e2p_boxes) { if (t.ent) (void)hipFree(t.ent); if (t.fb) (void)hipFree(t.fb); if (t.order) (void)hipFree(t.order); }
     if (g->e2p_fb_tiles) (void)hipFree(g->e2p_fb_tiles);
     if (g->e2p_ixy) (void)hipFree(g->e2p_ixy);
     delete g;

@@ -32,9 +32,10 @@ struct OmniOptions {
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
     int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 1: plain scatter backward
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
+    int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
+    int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
-    int p2e_bpc;          // OMNI_P2E_BPC        persistent blocks per CU of the pers2equi LDS kernel: 0 = what the occupancy API reports
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
 OmniOptions& omni_options();
@@ -78,7 +79,11 @@ struct omni_geometry {
     // bilinear taps inside the patch (omni_pers2equi.hip); index 0: 4-byte elements, 1: 2-byte elements (16-byte chunk alignment)
     struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; } p2e_tiles[2];
     int p2e_tx, p2e_ty;            // tiles per ERP row / column
-    int* e2p_fb_tiles;             // equi2pers: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box
+    // equi2pers LDS path (omni_equi2pers.hip, e2p_box_kernel): per (patch, sample tile) the bounding box of the bilinear taps on
+    // the ERP; index 0: 4-byte elements (8 x 32 sample tiles), 1: 2-byte elements (4 x 64); fb = tiles whose box exceeds the slot
+    struct E2PTiles { uint2* ent; int* fb; int nfb; int max_chunks; int tw, th, tx, ty; int ok;
+                      int* order; int norder; } e2p_boxes[2];   // order: LDS-path tiles grouped by ERP longitude sector, one sector per XCD (-1 = padding)
+    int* e2p_fb_tiles;             // equi2pers backward: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box
     int e2p_nfb;
     int e2p_ts;                    // equi2pers: tile side (32 or 16 samples) chosen so that the footprints fit the LDS box
     float2* e2p_ixy;               // equi2pers: clamped sampling coordinates (ix, iy) of every patch sample [N][ph][pw]
@@ -91,8 +96,9 @@ int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, floa
 int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream);
 // implemented in omni_pers2equi.hip: fills g->p2e_tiles (needs g->cand)
 int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream);
-// implemented in omni_equi2pers.hip: fills g->e2p_fb_tiles / e2p_nfb
+// implemented in omni_equi2pers.hip: fills g->e2p_ixy, g->e2p_fb_tiles / e2p_nfb, then g->e2p_boxes
 int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream);
+int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream);
 
 // ---------------------------------------------------------------- storage types
 template <typename T> struct Store;

@@ -64,7 +64,10 @@ def test_pers2equi_golden(name):
     H, W = (int(v) for v in g["erp_size"])
     erp = pers2equi(t(g["pers"]), fov, nrows, (P, P), (H, W), "golden")
     assert erp.shape == g["erp"].shape
-    assert_close_outliers(erp.cpu().numpy(), g["erp"], tol=2e-4, max_tol=1.0, frac=1e-4, what=name)
+    # A pixel differs by more than round-off only when a validity predicate (0 < X < P, cos_c > 0) flips at a patch border
+    # (DESIGN d2).  Where >= 2 patches overlap the flipped patch carries at most half of the normalised weight, so the change is
+    # <= 0.5 * (value range = 1); only nrows = 3 has pixels covered by ONE patch next to uncovered ones (change up to the range).
+    assert_close_outliers(erp.cpu().numpy(), g["erp"], tol=2e-4, max_tol=1.0 if "n3" in name else 0.51, frac=1e-4, what=name)
     planar = t(g["pers"]).permute(0, 4, 1, 2, 3).contiguous()
     erp2 = pers2equi(planar, fov, nrows, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
     assert torch.equal(erp2, erp)
@@ -81,13 +84,13 @@ def test_known_answers_config1_golden():
     np.testing.assert_allclose(xyz.cpu().numpy()[:, :, ::8, ::8], g["xyz_sub"], atol=1e-4)
     np.testing.assert_allclose(uv.cpu().numpy()[:, :, ::8, ::8], g["uv_sub"], atol=1e-4)
     e = pers2equi(t(rng_uniform(101, (1, 1, 256, 256, 18))), (80, 80), 4, (256, 256), (512, 1024), "x").cpu().numpy()
-    assert_close_outliers(e[:, :, ::4, ::4], g["erp_sub"], tol=2e-4, max_tol=1.0, frac=1e-4)
-    assert_close_outliers(e[:, :, [0, 1, 255, 256, 510, 511], :], g["erp_rows"], tol=2e-4, max_tol=1.0, frac=1e-3)
+    assert_close_outliers(e[:, :, ::4, ::4], g["erp_sub"], tol=2e-4, max_tol=0.51, frac=1e-4)
+    assert_close_outliers(e[:, :, [0, 1, 255, 256, 510, 511], :], g["erp_rows"], tol=2e-4, max_tol=0.51, frac=1e-3)
     g3 = golden("G8_config3")
     p3, _, _, _ = equi2pers(t(rng_uniform(102, (1, 1, 1024, 2048))), (80, 80), 6, (256, 256))
     assert_close_outliers(p3.cpu().numpy()[:, :, ::8, ::8, :], g3["pers_sub"], tol=1e-3, max_tol=5e-2, frac=1e-4)
     e3 = pers2equi(t(rng_uniform(103, (1, 1, 256, 256, 46))), (80, 80), 6, (256, 256), (1024, 2048), "x").cpu().numpy()
-    assert_close_outliers(e3[:, :, ::8, ::8], g3["erp_sub"], tol=2e-4, max_tol=1.0, frac=1e-4)
+    assert_close_outliers(e3[:, :, ::8, ::8], g3["erp_sub"], tol=2e-4, max_tol=0.51, frac=1e-4)
     assert len(g3["erp_nan_idx"]) <= 8 and np.isfinite(e3).all()      # reference NaN pixels (q11) stay finite here
 
 
@@ -121,7 +124,7 @@ def test_pers2equi_vs_oracle(cfg):
     x = rng_uniform(9, (B, C, P, P, N))
     ref = co.pers2equi(x, (80, 80), nrows, (P, P), (H, W))
     got = pers2equi(t(x), (80, 80), nrows, (P, P), (H, W), "o").cpu().numpy()
-    assert_close_outliers(got, ref, tol=2e-4, max_tol=1.0, frac=1e-5, what=str(cfg), ref_nan_max=8 * B * C)
+    assert_close_outliers(got, ref, tol=2e-4, max_tol=1.0 if nrows == 3 else 0.51, frac=1e-5, what=str(cfg), ref_nan_max=8 * B * C)
     # consistent patches (what the model produces): strict 1e-3 gate
     erp = smooth_erp(10, B, C, H, W)
     xs, _, _, _ = co.equi2pers(erp, (80, 80), nrows, (P, P))
@@ -198,16 +201,94 @@ def test_properties_full_size():
     assert (rt - xs)[:, :, 64:448].abs().max().item() < 0.02
 
 
-def test_high_res_config5_shape_fp16():
-    """BASELINE config 5 (2048x4096, nrows=6, 512^2, fp16): properties only (the reference cannot
-    run this size: ~20 GB of tables)."""
+# ------------------------------------------------------------------ the launches bench.py times, against the C oracle
+@pytest.mark.parametrize("P", [256, 128])
+def test_benched_planar_launches_vs_oracle(P):
+    """bench.py's resample launches exactly: planar [B,N,C,P,P] layout, B = 8 panoramas of 512x1024, nrows 4, P = 256 (the metric's
+    patch size) and P = 128 (the model's): equi2pers_patches (e2p_box_kernel), pers2equi (p2e_lds_kernel), pers2equi_conf
+    (p2e_lds_kernel<CONF>) — VERDICT r1 weak #1."""
+    _, equi2pers_patches, pers2equi, pers2equi_conf, L = _ops()
+    co = _oracle()
+    B, H, W, nrows, N = 8, 512, 1024, 4, 18
+    pl = lambda a: np.ascontiguousarray(np.transpose(a, (0, 4, 1, 2, 3)))            # [B,C,h,w,N] -> [B,N,C,h,w]
+    x = smooth_erp(41, B, 3, H, W)
+    ref, _, _, _ = co.equi2pers(x, (80, 80), nrows, (P, P))
+    got = equi2pers_patches(t(x), (80, 80), nrows, (P, P), layout=L.LAYOUT_BNCHW)
+    assert got.shape == (B, N, 3, P, P)
+    assert np.abs(got.cpu().numpy() - pl(ref)).max() <= 1e-3                         # strict gate on smooth input
+    xn = rng_uniform(42, (B, 3, H, W))
+    refn, _, _, _ = co.equi2pers(xn, (80, 80), nrows, (P, P))
+    gotn = equi2pers_patches(t(xn), (80, 80), nrows, (P, P), layout=L.LAYOUT_BNCHW)
+    assert_close_outliers(gotn.cpu().numpy(), pl(refn), tol=1e-3, max_tol=5e-2, frac=5e-5, what=f"equi2pers planar P={P}")
+    # pers2equi on the patches the operator chain really sees (consistent patches: strict) and on i.i.d. noise (outlier gate)
+    d = ref[:, :1]
+    e_ref = co.pers2equi(d, (80, 80), nrows, (P, P), (H, W))
+    e = pers2equi(t(pl(d)), (80, 80), nrows, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
+    assert e.shape == (B, 1, H, W) and np.abs(e.cpu().numpy() - e_ref).max() <= 1e-3
+    dn = rng_uniform(43, (B, 1, P, P, N))
+    en_ref = co.pers2equi(dn, (80, 80), nrows, (P, P), (H, W))
+    en = pers2equi(t(pl(dn)), (80, 80), nrows, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
+    assert_close_outliers(en.cpu().numpy(), en_ref, tol=2e-4, max_tol=0.51, frac=1e-5, what=f"pers2equi planar P={P}")
+    # fused confidence blend, depth range [0, 8]
+    c = rng_uniform(44, (B, 1, P, P, N))
+    pc_ref = co.pers2equi_conf(8.0 * d * c, c, (80, 80), nrows, (P, P), (H, W))
+    pc = pers2equi_conf(t(pl(8.0 * d * c)), t(pl(c)), (80, 80), nrows, (P, P), (H, W), layout=L.LAYOUT_BNCHW)
+    assert_close_outliers(pc.cpu().numpy(), pc_ref, tol=1e-3, max_tol=4.1, frac=1e-5, what=f"pers2equi_conf planar P={P}")
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_high_res_config5_vs_oracle(dtype):
+    """BASELINE config 5 (2048x4096 ERP, nrows 6, 46 x 512^2 patches, fp16 and fp32) against the C oracle on a smooth panorama with
+    depth-like values in [0, 8] (above 1024x2048 the restatement is the golden).  fp16 storage: the 4e-3 gate of
+    SURVEY 8d (input rounding + output rounding of values <= 8: 2 x 2^-9 = 3.9e-3)."""
     _, equi2pers_patches, pers2equi, _, L = _ops()
+    co = _oracle()
     H, W, P, N = 2048, 4096, 512, 46
-    x = torch.full((1, 3, H, W), 0.5, device=DEV, dtype=torch.float16)
-    p = equi2pers_patches(x, (80, 80), 6, (P, P), layout=L.LAYOUT_BNCHW)
-    assert p.shape == (1, N, 3, P, P) and (p.float() - 0.5).abs().max().item() <= 1e-3
-    e = pers2equi(p[:, :, :1].contiguous(), (80, 80), 6, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
-    assert e.shape == (1, 1, H, W) and (e.float() - 0.5).abs().max().item() <= 1e-3
+    dt = getattr(torch, dtype)
+    tol = 1e-3 if dtype == "float32" else 4e-3
+    x = smooth_erp(51, 1, 1, H, W) * 8.0
+    ref, _, _, _ = co.equi2pers(x, (80, 80), 6, (P, P))                              # [1,1,P,P,N]
+    xin = t(x).to(dt)
+    got = equi2pers_patches(xin, (80, 80), 6, (P, P), layout=L.LAYOUT_BNCHW)
+    assert got.shape == (1, N, 1, P, P) and got.dtype == dt
+    want = np.transpose(ref, (0, 4, 1, 2, 3))
+    if dtype == "float16":                                                           # compare against the oracle on the fp16-rounded input
+        want = np.transpose(co.equi2pers(xin.float().cpu().numpy(), (80, 80), 6, (P, P))[0], (0, 4, 1, 2, 3))
+    assert np.abs(got.float().cpu().numpy() - want).max() <= tol
+    e_ref = co.pers2equi(np.transpose(want, (0, 2, 3, 4, 1)), (80, 80), 6, (P, P), (H, W))
+    pin = t(np.ascontiguousarray(want)).to(dt)
+    if dtype == "float16":
+        e_ref = co.pers2equi(np.transpose(pin.float().cpu().numpy(), (0, 2, 3, 4, 1)), (80, 80), 6, (P, P), (H, W))
+    e = pers2equi(pin, (80, 80), 6, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
+    assert e.shape == (1, 1, H, W) and e.dtype == dt
+    ok = np.isfinite(e_ref)                                                          # reference NaN pixels (cos_c == 0 exactly, DESIGN d1)
+    assert (~ok).sum() <= 16 and np.isfinite(e.float().cpu().numpy()).all()
+    assert np.abs(e.float().cpu().numpy() - e_ref)[ok].max() <= tol
+
+
+@pytest.mark.parametrize("cfg", [(8, 3, 512, 1024, 4, 256, "float32"), (2, 3, 512, 1024, 4, 128, "float32"), (1, 2, 1024, 2048, 6, 256, "float32"),
+                                 (2, 3, 256, 512, 5, 64, "float16"), (3, 2, 200, 336, 3, 64, "float32"), (5, 1, 128, 256, 4, 32, "float16")])
+def test_lds_and_gather_paths_give_the_same_bits(cfg):
+    """The LDS-staged kernels (e2p_box_kernel, p2e_lds_kernel) and the direct-gather kernels evaluate the same tap functions and the
+    same sums in the same order: torch.equal, whatever the tile/box decomposition (options e2p_gather / p2e_gather select the path)."""
+    _, equi2pers_patches, pers2equi, pers2equi_conf, L = _ops()
+    B, C, H, W, nrows, P, dtype = cfg
+    N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+    dt = getattr(torch, dtype)
+    x = t(rng_uniform(61, (B, C, H, W))).to(dt)
+    y = t(rng_uniform(62, (B, N, C, P, P))).to(dt)
+    c = t(rng_uniform(63, (B, N, 1, P, P))).to(dt)
+    outs = {}
+    try:
+        for g in (0, 1):
+            L.set_option("e2p_gather", g); L.set_option("p2e_gather", g)
+            outs[g] = (equi2pers_patches(x, 80, nrows, P, layout=L.LAYOUT_BNCHW),
+                       pers2equi(y, 80, nrows, P, (H, W), None, layout=L.LAYOUT_BNCHW),
+                       pers2equi_conf(y[:, :, :1].contiguous() * c, c, 80, nrows, P, (H, W), layout=L.LAYOUT_BNCHW))
+    finally:
+        L.set_option("e2p_gather", 0); L.set_option("p2e_gather", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------ edge cases and errors

@@ -173,6 +173,21 @@ def main():
 
     traffic, traffic_note = pmc_traffic(B)
 
+    # ---- the same step fed from HOST memory: decoded uint8 frames in pinned memory -> async H2D + /255 + CHW on a
+    # side stream (omnifusion_amd/data.py), double-buffered against the forward.  Reported next to the resident-input `value`,
+    # never as `value` (the PCIe-inclusive rate).
+    from omnifusion_amd.data import DeviceFeeder
+    host_frames = [torch.randint(0, 256, (B, ERP_H, ERP_W, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(4)]
+    nfeed = max(20, args.steps)
+    for _ in DeviceFeeder((host_frames[k % 4] for k in range(4)), (ERP_H, ERP_W), device=dev):
+        pass
+    torch.cuda.synchronize()
+    tf = time.perf_counter()
+    for frame_rgb in DeviceFeeder((host_frames[k % 4] for k in range(nfeed)), (ERP_H, ERP_W), device=dev):
+        net(frame_rgb, confidence=True)
+    torch.cuda.synchronize()
+    host_fed = B * nfeed / (time.perf_counter() - tf)
+
     # ---- BASELINE cfg 2 as written (ONE panorama per forward): latency-bound, reported next to the batched figure
     one = rgb[:1].contiguous()
     for _ in range(3):
@@ -197,6 +212,9 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
                    "streams_per_gpu": net.LANES if B >= 2 * net.LANES else 1},
         "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3},
+        "host_fed": {"panoramas_per_s_per_gpu": host_fed, "frac_of_resident": host_fed / (B * args.steps / dt),
+                     "note": "inputs arrive as decoded uint8 BGR frames in pinned host memory (1.5 MB per panorama over PCIe), H2D + /255 + "
+                             "HWC->CHW on a side stream, triple-buffered (omnifusion_amd/data.py DeviceFeeder)"},
         "batch1": {"ms_per_forward": b1_ms, "panoramas_per_s": 1e3 / b1_ms,
                    "note": "BASELINE cfg 2 literally: one 512x1024 panorama per forward on this GPU (latency of ~150 dependent launches)"},
         "roofline": {"bound": "mfma",

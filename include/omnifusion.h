@@ -229,6 +229,29 @@ int omni_masked_median_f32(const float* x, const float* mask, size_t n, unsigned
 int omni_depth_metrics_f32(float* pred, const float* gt, const float* mask, const float* scale_num, const float* scale_den,
                            size_t n, double* ws, float* out, omni_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Host-facing ends of the hot path, csrc/omni_io.hip.
+ *
+ * omni_preprocess_rgb_u8: decoded BGR uint8 frames [B,Hs,Ws,3] (device memory; the Python side stages them through pinned
+ * buffers on a copy stream) -> cv2.INTER_AREA down-scale to HxW (identity when equal) -> /255 -> float32 [B,3,H,W].
+ * Replaces dataset_loader_stanford.py:54,85,92-97 (`readRGBPano`, `rgb.astype(np.float32)/255`, transpose(2,0,1)).
+ * omni_preprocess_depth_u16: 16-bit depth frames [B,Hs,Ws] -> float32 -> INTER_AREA -> /65535*128 -> mask (min, max] ->
+ * depth [B,1,H,W] (* mask) and mask uint8.  Replaces dataset_loader_stanford.py:76-80,99-109. */
+int omni_preprocess_rgb_u8(const unsigned char* src_hwc, float* dst_chw, int B, int Hs, int Ws, int H, int W, omni_stream_t stream);
+int omni_preprocess_depth_u16(const unsigned short* src, float* depth, unsigned char* mask, int B, int Hs, int Ws, int H, int W,
+                              float min_depth, float max_depth, omni_stream_t stream);
+/* Reverse-Huber loss of supervision/direct.py:3-18 (train_erp_depth.py:267): *loss = mean_b(sum(loss * mask * weights)_b / sum(mask)_b)
+ * with c = max|gt - pred| / 5 evaluated on the device.  `workspace` (omni_berhu_workspace_bytes(B) bytes) carries c and the
+ * per-item counts to omni_berhu_grad_f32, which writes dloss/dpred * (*grad_out). */
+size_t omni_berhu_workspace_bytes(int B);
+int omni_berhu_loss_f32(const float* pred, const float* gt, const float* mask, const float* weights, int B, size_t per_item,
+                        void* workspace, float* loss, omni_stream_t stream);
+int omni_berhu_grad_f32(const float* pred, const float* gt, const float* mask, const float* weights, int B, size_t per_item,
+                        const void* workspace, const float* grad_out, float* grad_pred, omni_stream_t stream);
+/* Point cloud of test.py:210-240: depth [B,1,H,W], rgb [B,3,H,W] -> B*H*W packed 15-byte PLY vertex records
+ * (x, y, z float32 = uv2xyz(coords2uv(pixel)) * depth, util.py:159-174; three uint8 colours = uint8(rgb * 255)). */
+int omni_pointcloud_ply_f32(const float* depth, const float* rgb, unsigned char* records, int B, int H, int W, omni_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     for (int k = 0; k < NPX; ++k) {
         l1[k] = 0.0f;
 #pragma unroll
-        for (int p = 0; p < PL; ++p) { acc[p][k] = 0.0f; if (CONF) acc2[p][k] = 0.0f; }
+        for (int p = 0; p < PL; ++p) { acc[p][k] = 0.0f; if constexpr (CONF) acc2[p][k] = 0.0f; }
     }
 
     for (int c = 0; c < ncand; ++c) {
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
                     LdsPair<T>::ld(box, r1[k], bx, by);
                     // taps (y0,x0) (y1,x0) (y0,x1) (y1,x1) in the gather kernel's order of operations
                     acc[P][k] += fmaf(by, wd[k], fmaf(ay, wc[k], fmaf(bx, wb[k], ax * wa[k])));
-                    if (CONF) {
+                    if constexpr (CONF) {
                         const unsigned char* box2 = box + (unsigned)slot_chunks * 16u;
                         LdsPair<T>::ld(box2, r0[k], ax, ay);
                         LdsPair<T>::ld(box2, r1[k], bx, by);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
             const size_t o = (size_t)(p_begin + p) * erp_plane + pix;
-            if (CONF) {
+            if constexpr (CONF) {
                 const float pr = acc[p][k] * rden, cf = acc2[p][k] * rden;
                 const float z = (cf <= 1e-8f) ? 1.0f : 0.0f;
                 reinterpret_cast<float*>(a.erp)[o] = pr / (cf + 1e-8f * z);

@@ -71,6 +71,21 @@ class DepthMetrics:
         self.count += n.double()
         return m
 
+    def averages_all_ranks(self):
+        """averages over the meters of every rank of an image-sharded run (omnifusion_amd/dist.py): sums of val*N and of N are
+        all-reduced once, at the end — not on the data path"""
+        import torch.distributed as dist
+        if self.sum is None:
+            raise RuntimeError("no batch has been evaluated on this rank")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.cat([self.sum, self.count.reshape(1)])
+            if dist.get_backend() != "nccl":
+                t = t.cpu()
+            dist.all_reduce(t)
+            t = t.to(self.sum.device)
+            return dict(zip(NAMES, (t[:7] / t[7]).cpu().tolist()))
+        return self.averages()
+
     def averages(self):
         if self.sum is None:
             return {k: float("nan") for k in NAMES}

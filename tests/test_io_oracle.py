@@ -1,0 +1,44 @@
+"""CPU: the oracle restatements of the host-facing ends (oracle/io_ref.py) against golden vectors produced by the reference's own
+code (G12 BerHu incl. autograd from supervision/direct.py, G13 point cloud from util.py / ply.py; oracle/gen_golden_io.py), and the
+algebraic properties of the INTER_AREA restatement (cv2 is not installed: parity unpinned for that function, see io_ref.py)."""
+import numpy as np
+
+from _util import golden
+from oracle import io_ref
+
+
+def test_berhu_restatement_golden():
+    g = golden("G12_berhu")
+    loss, grad = io_ref.berhu_loss(g["pred"], g["gt"], g["mask"], g["weights"])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert np.abs(grad - g["grad"]).max() <= 1e-8
+    assert grad[1, 0, 3, 5] == 0.0                                       # exact hit: sign(0) = 0
+
+
+def test_pointcloud_restatement_golden():
+    g = golden("G13_pointcloud")
+    pts, col = io_ref.pointcloud(g["depth"], g["rgb"])
+    assert np.abs(pts - g["pts"]).max() <= 1e-6 and np.array_equal(col, g["col"])
+    # the reference's PLY bytes: header + packed 15-byte records of item 0
+    raw = g["ply0"].tobytes()
+    head, body = raw.split(b"end_header\n")
+    assert b"element vertex 512" in head and b"property float32 x" in head and b"property uint8 red" in head
+    rec = np.frombuffer(body, np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("blue", "u1"), ("green", "u1"), ("red", "u1")]))
+    assert rec.shape[0] == 512 and np.array_equal(rec["blue"], g["col"][0, :, 0]) and np.allclose(rec["z"], g["pts"][0, :, 2])
+
+
+def test_inter_area_properties():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    assert np.array_equal(io_ref.inter_area(img, 32, 64), img)           # identity
+    box = img.reshape(8, 4, 16, 4, 3).astype(np.float32).mean((1, 3))    # integer scale = box average, rounded to nearest-even
+    assert np.array_equal(io_ref.inter_area(img, 8, 16), np.rint(box).astype(np.uint8))
+    half = img.reshape(16, 2, 32, 2, 3).astype(np.int32).sum((1, 3))
+    assert np.array_equal(io_ref.inter_area(img, 16, 32), ((half + 2) >> 2).astype(np.uint8))      # 2x2 fast path rounds half up
+    const = np.full((30, 50), 1234, np.uint16)
+    assert np.array_equal(io_ref.inter_area(const, 7, 11), np.full((7, 11), 1234, np.uint16))      # fractional scale: weights sum to 1
+    f = rng.random((30, 50)).astype(np.float32)
+    r = io_ref.inter_area(f, 7, 11)
+    assert abs(float(r.mean()) - float(f[:28, :].mean())) < 0.05 and r.min() >= f.min() and r.max() <= f.max()
+    d, m = io_ref.preprocess_depth(np.array([[[0, 51, 4000, 5000]]], np.uint16), 1, 4)
+    assert m.reshape(-1).tolist() == [0, 0, 1, 0] and abs(float(d[0, 0, 0, 2]) - 4000 / 65535 * 128) < 1e-5

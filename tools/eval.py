@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Evaluation harness — the loop of /root/reference/test.py:193-203,244-258 on the MI355X path.
+
+    python tools/eval.py [--checkpoint ckpt.pth] [--iterative --iter 2] [--batches 8 --batch 4] [--ply-every 20 --out results/]
+                         [--from-host]  [--gpus N]
+
+    network = spherical_fusion(...); network.load_state_dict(ckpt); network.cuda(); network.eval()          test.py:104-111
+    for rgb, depth, mask in loader:                                                                         test.py:195
+        equi_outputs = network(rgb[, iter])[-1]                                                             test.py:198-199
+        compute_eval_metrics(equi_outputs, depth, mask)        # median scaling + 7 metrics, on the device  test.py:203
+        every --ply-every batches: point cloud of item 0 -> PLY                                             test.py:210-240
+    print the seven averages                                                                                test.py:244-258
+
+There is no dataset in this image (Stanford2D3D is not redistributable and there is no network): without --data the loader yields
+Stanford2D3D-SHAPED synthetic frames — uint8 BGR 512x1024 (or larger with --src-scale) and 16-bit depth — through the same device
+pipeline a real loader would feed (omnifusion_amd/data.py: pinned H2D + INTER_AREA + /255 on a side stream); weights are the
+deterministic random-init generator unless --checkpoint names a reference state_dict.  With --gpus N the batches are sharded by
+image over N ranks (omnifusion_amd/dist.py) and the meters are summed over ranks at the end.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def synthetic_batches(n, B, H, W, scale, seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        rgb = rng.integers(0, 256, (B, H * scale, W * scale, 3), dtype=np.uint8)
+        depth = rng.integers(60, 4090, (B, H * scale, W * scale), dtype=np.uint16)      # 0.12 .. 7.99 m
+        yield rgb, depth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--iterative", action="store_true"); ap.add_argument("--iter", type=int, default=2)
+    ap.add_argument("--nrows", type=int, default=4); ap.add_argument("--patchsize", type=int, default=128); ap.add_argument("--fov", type=float, default=80.0)
+    ap.add_argument("--batches", type=int, default=8); ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--height", type=int, default=512); ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--src-scale", type=int, default=1, help="decoded frames are this many times larger than the network input (INTER_AREA on the device)")
+    ap.add_argument("--ply-every", type=int, default=0); ap.add_argument("--out", default="results")
+    ap.add_argument("--gpus", type=int, default=1)
+    args = ap.parse_args()
+    from omnifusion_amd import dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(dist.respawn_under_launcher(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    assert torch.cuda.is_available(), "tools/eval.py needs an MI355X (no CPU fallback exists)"
+    rank, local, world, dev = dist.init(os.environ.get("OMNI_BENCH_DIST_BACKEND", "nccl"))
+
+    from omnifusion_amd.data import DeviceFeeder, preprocess_depth
+    from omnifusion_amd.eval import DepthMetrics
+    from omnifusion_amd.ply import write_ply_pointcloud
+    from omnifusion_amd.weights import make_state_dict
+    N = {3: 10, 4: 18, 5: 26, 6: 46}[args.nrows]
+    if args.iterative:
+        from omnifusion_amd.model.spherical_model_iterative import spherical_fusion
+    else:
+        from omnifusion_amd.model.spherical_model import spherical_fusion
+    network = spherical_fusion(args.nrows, N, (args.patchsize, args.patchsize), (args.fov, args.fov))        # test.py:104
+    sd = torch.load(args.checkpoint, map_location="cpu") if (args.checkpoint and rank == 0) else (make_state_dict(42, N, args.iterative) if rank == 0 else None)
+    sd = dist.broadcast_state_dict(sd, src=0)                                                                # one reader, RCCL broadcast
+    network.load_state_dict(sd)
+    network.cuda(dev.index); network.eval()                                                                  # test.py:110-111,194
+
+    lo, hi = dist.shard(args.batch, rank, world)                                                             # image sharding of every batch
+    frames = [(r[lo:hi], d[lo:hi]) for r, d in synthetic_batches(args.batches, args.batch, args.height, args.width, args.src_scale, 1234)]
+    meters = DepthMetrics()
+    os.makedirs(args.out, exist_ok=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    feeder = DeviceFeeder((r for r, _ in frames), (args.height, args.width), device=dev)
+    for batch_idx, rgb in enumerate(feeder):
+        d16 = torch.from_numpy(frames[batch_idx][1].view(np.int16)).to(dev, non_blocking=True)
+        depth, mask = preprocess_depth(d16, (args.height, args.width))                                       # loader :76-80,99-109
+        with torch.no_grad():
+            out = network(rgb, iter=args.iter)[-1] if args.iterative else network(rgb)                       # test.py:198-199
+            if args.ply_every and batch_idx % args.ply_every == 0 and rank == 0:
+                write_ply_pointcloud(os.path.join(args.out, f"test_pred_{batch_idx}"), out, rgb)             # test.py:233-238 (before the in-place scaling)
+            meters.update(out, depth, mask.to(torch.float32))                                                # test.py:203
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    avg = meters.averages() if world == 1 else meters.averages_all_ranks()
+    if rank == 0:
+        print('  Avg. Abs. Rel. Error: {:.4f}\n  Avg. Sq. Rel. Error: {:.4f}\n  Avg. Lin. RMS Error: {:.4f}\n  Avg. Log RMS Error: {:.4f}\n'
+              '  Inlier D1: {:.4f}\n  Inlier D2: {:.4f}\n  Inlier D3: {:.4f}\n'.format(
+                  avg["abs_rel"], avg["sq_rel"], math.sqrt(avg["rms_sq_lin"]), math.sqrt(avg["rms_sq_log"]), avg["d1"], avg["d2"], avg["d3"]))
+        print(f"{args.batches * args.batch} panoramas in {dt:.3f} s ({args.batches * args.batch / dt:.1f} panoramas/s incl. host staging, {world} rank(s))")
+        if network.overflowed():
+            print("WARNING: activations left the fp16 range of the f16x3 format (saturated): rerun with OMNI_NET_PRECISION=fp32")
+    dist.finalize()
+
+
+if __name__ == "__main__":
+    main()

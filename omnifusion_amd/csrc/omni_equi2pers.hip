@@ -970,16 +970,19 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
         (void)hipFree(dstats);
         tt.max_chunks = hs[0]; tt.nfb = hs[1];
         {
-            // LDS-path tiles grouped by the ERP longitude sector (W/8 columns each) of their box centre, one sector per XCD; inside a
-            // sector by latitude (box row), then longitude: tiles that run at the same time read neighbouring boxes
+            // LDS-path tiles grouped by the ERP REGION of their box centre, one region per XCD: 4 longitude sectors x 2 hemispheres
+            // (a box is ~40-100 x 10 pixels: few boxes straddle the borders of a 256 x H/2 region, whereas with 8 longitude strips
+            // of W/8 columns every second box did and was fetched by two XCDs).  Inside a region by latitude band, then longitude:
+            // tiles that run at the same time read neighbouring boxes.
             std::vector<uint2> he((size_t)ntiles);
             OMNI_HIP(hipMemcpy(he.data(), tt.ent, sizeof(uint2) * (size_t)ntiles, hipMemcpyDeviceToHost));
             std::vector<std::vector<std::pair<unsigned, int>>> sec(8);
             for (int i = 0; i < (int)ntiles; ++i) {
                 if (!(he[i].x >> 31)) continue;
-                const int xs4 = (int)(he[i].y & 0xffff), ymin = (int)(he[i].y >> 16), bw = (int)(he[i].x & 4095) * epc;
+                const int xs4 = (int)(he[i].y & 0xffff), ymin = (int)(he[i].y >> 16), bw = (int)(he[i].x & 4095) * epc, bh = (int)((he[i].x >> 12) & 4095);
                 int xc = xs4 + bw / 2; if (xc >= g->W) xc -= g->W;
-                const int sx = (int)((long long)xc * 8 / g->W) & 7;
+                const int yc = ymin + bh / 2;
+                const int sx = ((int)((long long)xc * 4 / g->W) & 3) + 4 * (yc * 2 >= g->H ? 1 : 0);
                 sec[sx].push_back({((unsigned)(ymin / 8) << 16) | (unsigned)xc, i});
             }
             size_t mx = 0;

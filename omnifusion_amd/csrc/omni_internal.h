@@ -129,7 +129,7 @@ __device__ __forceinline__ unsigned omni_xcd_remap(unsigned bid, unsigned nblock
 // (interleaving single tile rows measured 3.6x the compulsory HBM traffic).  So the image is cut into bands of `band` tile rows,
 // XCD x (blocks = x mod 8) owns bands x, x+8, x+16, ... and walks each band row by row.
 // Launch omni_xcd_bands_grid() blocks; false = padding block (row past the end).
-__host__ __device__ inline int omni_xcd_band_rows(int rows) { const int b = rows / 32; return b < 1 ? 1 : (b > 8 ? 8 : b); }
+__host__ __device__ inline int omni_xcd_band_rows(int rows) { const int b = rows / 16; return b < 1 ? 1 : (b > 8 ? 8 : b); }
 __host__ __device__ inline int omni_xcd_rows_grid(int rows, int cols)
 {
     const int band = omni_xcd_band_rows(rows);

@@ -226,7 +226,7 @@ def main():
                      "note": ("algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product: "
                               f"{3 * tflops:.0f} of {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s fp16 dense issued") if f16x3 else
                              "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
-        "roofline_resample": {"bound": "hbm", "kernel": "e2p_lds_kernel + p2e_kernel<float,8,false,true> at 18x256^2, B=%d" % B,
+        "roofline_resample": {"bound": "hbm", "kernel": "e2p_box_kernel<float,2> + p2e_lds_kernel<float,8,false,2> at 18x256^2, B=%d (planar layout)" % B,
                               "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
                               # HBM bytes per launch pair from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE doubled as
                               # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), written by tools/pmc_traffic.sh

@@ -526,7 +526,13 @@ template <> struct E2BPair<float> {
 };
 template <> struct E2BPair<__half> {
     static __device__ __forceinline__ void ld(const unsigned char* b, int o, float& x, float& y)
-    { const __half* p = reinterpret_cast<const __half*>(b) + o; x = __half2float(p[0]); y = __half2float(p[1]); }
+    {   // halfs o, o+1: one ds_read2_b32 of the two 32-bit words around them + a byte-align
+        const unsigned* p = reinterpret_cast<const unsigned*>(b) + (o >> 1);
+        const unsigned w0 = p[0], w1 = p[1];
+        const unsigned v = (o & 1) ? __builtin_amdgcn_alignbyte(w1, w0, 2u) : w0;
+        const __half2 h = *reinterpret_cast<const __half2*>(&v);
+        x = __low2float(h); y = __high2float(h);
+    }
 };
 
 // clamped sampling coordinate of sample (n, h, w): from the per-geometry table, or evaluated on the fly (same function, same bits)

@@ -329,8 +329,16 @@ template <> struct LdsPair<float> {
     { const float* p = reinterpret_cast<const float*>(b) + o; x = p[0]; y = p[1]; }              // one ds_read2_b32
 };
 template <> struct LdsPair<__half> {
+    // halfs o, o+1: one ds_read2_b32 of the two 32-bit words around them + a byte-align (no 16-bit LDS reads, which cost a full
+    // LDS instruction each)
     static __device__ __forceinline__ void ld(const unsigned char* b, int o, float& x, float& y)
-    { const __half* p = reinterpret_cast<const __half*>(b) + o; x = __half2float(p[0]); y = __half2float(p[1]); }
+    {
+        const unsigned* p = reinterpret_cast<const unsigned*>(b) + (o >> 1);
+        const unsigned w0 = p[0], w1 = p[1];
+        const unsigned v = (o & 1) ? __builtin_amdgcn_alignbyte(w1, w0, 2u) : w0;
+        const __half2 h = *reinterpret_cast<const __half2*>(&v);
+        x = __low2float(h); y = __high2float(h);
+    }
 };
 
 typedef __amdgpu_buffer_rsrc_t p2e_rsrc_t;

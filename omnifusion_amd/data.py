@@ -63,50 +63,57 @@ def preprocess_depth(frames_u16, size, min_depth=0.1, max_depth=8.0):
 
 
 class DeviceFeeder:
-    """Pinned, multi-buffered host -> device staging of decoded frames + the preprocess kernel on a copy stream."""
+    """Pinned, multi-buffered host -> device staging of decoded frames on a copy stream; /255 + HWC->CHW on the consumer's stream.
+
+    The yielded tensor is ONE reusable float32 buffer: it is valid until the next batch is requested (stream order on the
+    consumer's current stream guarantees that the previous forward has read it before it is overwritten) — clone it to keep it.
+    Device footprint: `depth` uint8 frames + one float32 batch (the 256 MB Infinity Cache also holds the network's weights and
+    activations: a float32 buffer per slot measurably slows the forward down)."""
 
     def __init__(self, batches, size, device=None, depth=3):
         self.batches, self.size, self.depth = batches, _hw(size), max(2, int(depth))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
         self._slots = None
+        self._out = None
 
     def _alloc(self, shape):
         B, Hs, Ws, _ = shape
         H, W = self.size
-        self._slots = [{"pin": torch.empty(shape, dtype=torch.uint8).pin_memory(),
-                        "dev": torch.empty(shape, dtype=torch.uint8, device=self.device),
-                        "out": torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device),
+        self._slots = [{"pin": None, "dev": torch.empty(shape, dtype=torch.uint8, device=self.device),
                         "ready": torch.cuda.Event(), "free": None} for _ in range(self.depth)]
-        self._last = None
+        self._out = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
 
     def _stage(self, slot, frames):
         s = self._slots[slot]
-        if s["free"] is not None:
-            s["free"].synchronize()                                    # the consumer is done with this slot's output
         if isinstance(frames, torch.Tensor) and frames.is_pinned():
             # a DataLoader(pin_memory=True) batch: already page-locked, copied to the device straight from where the worker put it
-            if frames.dtype != torch.uint8 or tuple(frames.shape) != tuple(s["pin"].shape):
+            if frames.dtype != torch.uint8 or tuple(frames.shape) != tuple(s["dev"].shape):
                 raise ValueError("pinned batches must be uint8 [B,Hs,Ws,3] of one shape")
             src = frames
         else:
             a = np.ascontiguousarray(frames.numpy() if isinstance(frames, torch.Tensor) else frames)
             if a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3:
                 raise ValueError("batches must yield uint8 arrays [B,Hs,Ws,3]")
-            if tuple(s["pin"].shape) != a.shape:
+            if tuple(s["dev"].shape) != a.shape:
                 raise ValueError("all batches of one feeder must have the same shape")
+            if s["pin"] is None:
+                s["pin"] = torch.empty(a.shape, dtype=torch.uint8).pin_memory()
+            if s["free"] is not None:
+                s["free"].synchronize()                                # (the previous H2D out of this pinned buffer has been consumed)
             s["pin"].numpy()[...] = a                                  # host memcpy into pinned memory (the worker's hand-over)
             src = s["pin"]
+        if s["free"] is not None:
+            self.side.wait_event(s["free"])                            # the consumer's preprocess has read this slot's device frame
         with torch.cuda.stream(self.side):
             s["dev"].copy_(src, non_blocking=True)                     # async H2D on the side stream
-            preprocess_rgb(s["dev"], self.size, out=s["out"])
             s["ready"].record(self.side)
+        s["src"] = src                                                 # keep the host buffer alive until the copy has been ordered
 
     def __iter__(self):
-        it = iter(self.batches)
         pending = []
         k = 0
-        for frames in it:
+        for frames in self.batches:
             if self._slots is None:
                 self._alloc(tuple(frames.shape))
             self._stage(k % self.depth, frames)
@@ -120,11 +127,7 @@ class DeviceFeeder:
     def _hand_over(self, slot):
         s = self._slots[slot]
         cur = torch.cuda.current_stream(self.device)
-        # the batch handed over LAST time has been consumed by everything enqueued on `cur` up to now: its slot becomes reusable
-        # once that work is done (the event is waited for — on the host — only when the slot comes around again, depth-1 batches later)
-        prev = getattr(self, "_last", None)
-        if prev is not None:
-            ev = torch.cuda.Event(); ev.record(cur); self._slots[prev]["free"] = ev
-        self._last = slot
         cur.wait_event(s["ready"])                                     # no host synchronisation
-        return s["out"]
+        preprocess_rgb(s["dev"], self.size, out=self._out)             # 35 us at 8 x 512x1024; behind the previous forward in stream order
+        ev = torch.cuda.Event(); ev.record(cur); s["free"] = ev        # the slot's device frame may be overwritten after this point
+        return self._out

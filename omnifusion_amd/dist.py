@@ -52,7 +52,9 @@ def init(backend=None):
         local_dev = local % ndev                     # gloo: several ranks may share a GPU (single-GPU test boxes)
         torch.cuda.set_device(local_dev)
         device = torch.device("cuda", local_dev)
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (WORLD_SIZE set) the group is created even for ONE rank: the RCCL bring-up, the barrier and the MAX
+    # all-reduce of the timing protocol then run on a single-GPU box exactly as they do on eight
+    if (world > 1 or "WORLD_SIZE" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -70,16 +72,20 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _grouped():
+    return dist.is_available() and dist.is_initialized()
+
+
 def _coll_device(device=None):
     """device a collective's tensors must live on for the active backend"""
-    if _world() > 1 and dist.get_backend() == "nccl":
+    if _grouped() and dist.get_backend() == "nccl":
         return device if device is not None and torch.device(device).type == "cuda" else torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
 
 
 def barrier_sync(device=None):
     """barrier over the ranks, then drain this rank's GPU: both sides of the timed region"""
-    if _world() > 1:
+    if _grouped():
         dist.barrier()
     if torch.cuda.is_available():
         torch.cuda.synchronize(device)
@@ -87,7 +93,7 @@ def barrier_sync(device=None):
 
 def reduce_max(value, device=None):
     """MAX over ranks of a Python float (the job is as slow as its slowest rank)"""
-    if _world() == 1:
+    if not _grouped():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

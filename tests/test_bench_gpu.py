@@ -47,3 +47,20 @@ def test_bench_rejects_world_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_bench_under_launcher_one_rank_rccl():
+    """The driver's launch form with N = 1: torch.distributed.run starts one rank, the process group is RCCL (backend nccl), and the
+    barrier + MAX all-reduce of the timing protocol run on the device — the same calls the 8-GPU launch makes."""
+    sys.path.insert(0, ROOT)
+    from omnifusion_amd import dist
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMNI_BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = dist.launch_command(os.path.join(ROOT, "bench.py"), ["--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--no-cpu-baseline"], 1)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0

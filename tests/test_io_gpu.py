@@ -73,8 +73,7 @@ def test_device_feeder_delivers_every_batch_in_order():
     outs = []
     for rgb in DeviceFeeder(batches, (32, 64), depth=3):
         assert rgb.is_cuda and rgb.shape == (2, 3, 32, 64)
-        outs.append((rgb * 2.0).sum().item())                               # consume on the current stream
-        outs[-1] = (outs[-1], rgb.clone())
+        outs.append(((rgb * 2.0).sum(), rgb.clone()))                        # consume on the current stream (the buffer is reused: clone to keep)
     assert len(outs) == 7
     for (_, got), fr in zip(outs, batches):
         assert np.array_equal(got.cpu().numpy(), io_ref.preprocess_rgb(fr, 32, 64))

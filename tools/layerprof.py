@@ -4,12 +4,12 @@ usage: python tools/layerprof.py gpurun_out/prof_x/**/x_kernel_trace.csv"""
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "e2p_lds_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "e2p_box_kernel" in r["Kernel_Name"] or "e2p_lds_kernel" in r["Kernel_Name"]]
 # last forward = from the last e2p at P=128 (grid differs from P=256) .. next p2e kernel
 start = None
 for i in reversed(idx):
     start = i
-    nxt = [j for j in range(i + 1, len(rows)) if "p2e_kernel" in rows[j]["Kernel_Name"]]
+    nxt = [j for j in range(i + 1, len(rows)) if "p2e_lds_kernel" in rows[j]["Kernel_Name"] or "p2e_kernel" in rows[j]["Kernel_Name"]]
     if nxt and nxt[0] - i > 50:
         end = nxt[0]
         break

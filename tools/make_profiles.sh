@@ -1,25 +1,31 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/make_profiles.sh <tag>
-# Writes gpurun_out/<tag>_bench.json, <tag>_bench_kernel_stats.txt, <tag>_layers.txt, <tag>_conv_pmc.txt, <tag>_resample_pmc.txt
+# Writes into gpurun_out/: <tag>_bench.json, <tag>_bench_kernel_stats.txt (rocprofv3 --kernel-trace --stats of the same bench command),
+# <tag>_layers_b8.txt / <tag>_layers_b1.txt (kernel sequence of ONE forward at 8 / 1 panoramas), <tag>_resample_shapes.txt (per-shape
+# durations of the resample pair), <tag>_resample_pmc.txt (counters), <tag>_resample_traffic.json (HBM bytes + build hash).
 tag=$1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 python bench.py > $O/${tag}_bench.log 2>&1; tail -1 $O/${tag}_bench.log > $O/${tag}_bench.json
+tools/prof_bench.sh $tag > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-d=$O/prof_$tag; rm -rf $d; mkdir -p $d
-rocprofv3 --kernel-trace --stats --output-format csv -d $d -o $tag -- python $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $d.log 2>&1
-python - "$d" "$tag" > $O/${tag}_bench_kernel_stats.txt <<'PY'
-import csv, sys, glob
-d, tag = sys.argv[1], sys.argv[2]
-f = glob.glob(f"{d}/**/{tag}_kernel_stats.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-print(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 10 --warmup 3   (snapshot {tag})")
-print(f"{'kernel':104s}{'calls':>7s}{'total_us':>13s}{'avg_us':>11s}{'pct':>8s}")
-for r in rows:
-    print(f"{r['Name'][:102]:104s}{int(r['Calls']):7d}{float(r['TotalDurationNs'])/1e3:13.1f}{float(r['AverageNs'])/1e3:11.2f}{float(r['Percentage']):8.2f}")
-PY
-python $R/tools/layerprof.py $(find $d -name "${tag}_kernel_trace.csv" | head -1) v > $O/${tag}_layers.txt
+for b in 8 1; do
+  d=$O/prof_${tag}_b$b; rm -rf $d; mkdir -p $d
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $d -o l -- python $R/tools/fwd.py --batch $b --steps 6 > $d.log 2>&1
+  { echo "# kernel sequence of ONE forward of the single-pass model at $b panorama(s) per GPU (512x1024, 18 x 128^2 patches; two half-batch streams when >= 4):";
+    echo "# rocprofv3 --kernel-trace -- python tools/fwd.py --batch $b --steps 6, last forward; columns: kernel, grid (threads), duration us";
+    python $R/tools/layerprof.py $(find $d -name "l_kernel_trace.csv" | head -1) v; } > $O/${tag}_layers_b$b.txt
+done
 cd $R
-tools/pmc3.sh ${tag}c conv tools/convbench.py > $O/${tag}_conv_pmc.txt 2>&1
+{ echo "# resample pair, per shape: tools/kbench.py (HIP events on the launch stream, 20 launches each); algorithmic bytes = B*C*(H*W + P*P*N)*s per operator (SURVEY 8d)";
+  python tools/kbench.py --B 8 --P 256 --copy
+  python tools/kbench.py --B 8 --P 128
+  python tools/kbench.py --B 1 --P 256
+  python tools/kbench.py --B 16 --P 256
+  python tools/kbench.py --B 1 --P 256 --H 1024 --W 2048 --nrows 6
+  python tools/kbench.py --B 1 --P 512 --H 2048 --W 4096 --nrows 6
+  python tools/kbench.py --B 1 --P 512 --H 2048 --W 4096 --nrows 6 --half
+  python tools/kbench.py --B 4 --P 512 --H 2048 --W 4096 --nrows 6 --half; } 2>&1 | grep -v amdgpu.ids > $O/${tag}_resample_shapes.txt
 tools/pmc.sh ${tag}r --iters 5 > $O/${tag}_resample_pmc.txt 2>&1
+tools/pmc_traffic.sh $tag 8 > /dev/null 2>&1
 ls -la $O | grep $tag

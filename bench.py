@@ -100,9 +100,9 @@ def main():
     # one rank per GPU over RCCL.  (OMNI_BENCH_DIST_BACKEND=gloo lets the multi-rank path be exercised with several ranks
     # sharing one GPU on a single-GPU box; the real launch is nccl = RCCL with LOCAL_RANK == device index.)
     backend = os.environ.get("OMNI_BENCH_DIST_BACKEND", "nccl")
+    if dist.env_rank()[2] != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={dist.env_rank()[2]} ranks")
     rank, local, world, dev = dist.init(backend)
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local = dev.index
 
     from omnifusion_amd import _lib

@@ -5,8 +5,8 @@ pretrained=True)` (model/spherical_model.py:197) cannot download here, so tests 
 random-init weights of the reference architecture: `make_state_dict(seed, ...)` returns tensors
 named and shaped exactly like `spherical_fusion().state_dict()` of the reference
 (model/spherical_model.py:190-235 / model/spherical_model_iterative.py:253-305; 363 / 375
-tensors, conv weights 5-D `[O,I,k,k,1]`) — tests/test_model_schema.py checks the schema against a
-listing taken from the reference itself (tests/golden/state_dict_schema_*.json).
+tensors, conv weights 5-D `[O,I,k,k,1]`) — tests/test_model_oracle.py and tests/test_module_api.py check the schema (names, shapes,
+ORDER) against a listing taken from the reference itself (tests/golden/state_dict_schema_*.json).
 
 Values come from numpy's PCG64 seeded per tensor name (stable across numpy / torch versions).
 Scales are He-style so activations neither vanish nor explode through the 50-odd layers, BN

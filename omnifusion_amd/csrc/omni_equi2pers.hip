@@ -544,23 +544,44 @@ __device__ __forceinline__ void e2b_xy(const E2PArgs& a, int n, int h, int w, fl
 
 // table entry of one tile: x = bw4 | bh << 12 | fits << 31 (bw4 = 16-byte chunks per box row, bh = box rows),
 //                          y = xs4 | ymin << 16 (first box column, chunk-aligned, the box wraps at the seam; first box row)
-// lane -> samples: the tile is E2B_TH = 8 rows x E2B_TW = 32 columns; lane l owns the 4 horizontally adjacent samples
-// (row l / 8, columns 4 (l % 8) .. +3): ONE 16-byte (fp16: 8-byte) store per lane and plane, 128-byte (64-byte) row segments
+// the tile is E2B_TH = 8 rows x E2B_TW = 32 columns of samples, 4 per lane; every lane stores 4 adjacent samples of ONE row: one 16-byte
+// (fp16: 8-byte) store per lane and plane.  Two lane -> sample maps (e2p_box_kernel's ROWMAP); for the second one the 4x4 block (4 rows x 4
+// columns) held by each quad of lanes is transposed with DPP moves before the store.
 constexpr int E2B_TH = 8, E2B_TW = 32;
 
+__device__ __forceinline__ float e2b_dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float e2b_dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+// r[k] of lane i (i = lane % 4)  ->  r[k] = what lane k of the quad held in r[i]
+__device__ __forceinline__ void e2b_quad_transpose(float (&r)[4], int lane)
+{
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                                  // 2x2 blocks: exchange M[2p][2q+1] <-> M[2p+1][2q]
+        const float y = e2b_dpp_xor1(o1 ? r[2 * q] : r[2 * q + 1]);
+        r[2 * q + 1] = o1 ? r[2 * q + 1] : y;
+        r[2 * q] = o1 ? y : r[2 * q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                                  // off-diagonal 2x2 blocks: M[p][q+2] <-> M[p+2][q]
+        const float y = e2b_dpp_xor2(o2 ? r[q] : r[q + 2]);
+        r[q + 2] = o2 ? r[q + 2] : y;
+        r[q] = o2 ? y : r[q];
+    }
+}
+
 __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __restrict__ ent, int tiles_x, int tiles_pp, int ntiles, int epc,
-                                                        int cap_chunks, int* __restrict__ stats)
+                                                        int cap_chunks, int odd_pitch, int* __restrict__ stats)
 {
     const int wid = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (wid >= ntiles) return;
     const int n = wid / tiles_pp, t = wid - n * tiles_pp;
     const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
-    const int h = min(th0 + (lane >> 3), a.ph - 1);
+    const int w = min(tw0 + (lane & 31), a.pw - 1);
     const int W = a.W, H = a.H, half = W >> 1;
     int x0[E2B_NPX], ymin = 0x7fffffff, ymax = -1;
 #pragma unroll
     for (int k = 0; k < E2B_NPX; ++k) {
-        const int w = min(tw0 + 4 * (lane & 7) + k, a.pw - 1);
+        const int h = min(th0 + (lane >> 5) + 2 * k, a.ph - 1);
         float ix, iy;
         e2b_xy(a, n, h, w, ix, iy);
         const int y0 = (int)floorf(iy);                            // (NaN -> 0: ATen clips the NaN row coordinate of quirk q4 to 0)
@@ -585,7 +606,8 @@ __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __rest
     if (xs < 0) xs += W;
     if (xs >= W) xs -= W;
     const int xs4 = xs / epc * epc, shift = xs - xs4;
-    const int bw4 = (dmax - dmin + 2 + shift + epc - 1) / epc;     // columns x0 .. x0+1 of every sample, whole 16-byte chunks
+    int bw4 = (dmax - dmin + 2 + shift + epc - 1) / epc;           // columns x0 .. x0+1 of every sample, whole 16-byte chunks
+    if (odd_pitch && (bw4 & 1) == 0 && (bw4 + 1) * epc <= W) ++bw4;   // odd number of chunks per box row: consecutive rows start 4, 12, 20, 28 banks apart
     const int bh = ymax - ymin + 1;
     const bool fits = (W % epc == 0) && bw4 * epc <= W && bw4 < 4096 && bh < 4096 && bw4 * bh <= cap_chunks;
     if (lane == 0) {
@@ -605,7 +627,7 @@ template <> struct E2BStore4<__half> {
     { __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]); uint2 v; v.x = *reinterpret_cast<unsigned*>(&lo); v.y = *reinterpret_cast<unsigned*>(&hi); *reinterpret_cast<uint2*>(p) = v; }
 };
 
-template <typename T, int NB>
+template <typename T, int NB, bool ROWMAP>
 __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_pp,
                                                         const int* __restrict__ fb, int nfb_blocks, const int* __restrict__ order, int lds_start,
                                                         int slot_chunks, unsigned tensor_bytes)
@@ -629,7 +651,11 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
     const int n = wid / tiles_pp, t = wid - n * tiles_pp;
     const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
     const int W = a.W, H = a.H;
-    const int w = tw0 + 4 * (lane & 7), hb = th0 + (lane >> 3);
+    // lane -> samples.  ROWMAP (2-byte elements): lane computes (row lane/32 + 2k, column lane%32) — a half-wave, the conflict group of
+    // ds_read2_b32, reads the taps of 32 consecutive samples of one row — and the results are transposed inside each quad before the
+    // store.  Otherwise (4-byte elements) lane computes the 4 adjacent samples (row lane/8, columns 4 (lane%8) + k) it stores; measured
+    // per shape: fp32 22 vs 27 us at P = 128 and equal at P = 256 in favour of the direct form, fp16 cfg5 72 vs 126 us in favour of ROWMAP.
+    const int w = ROWMAP ? tw0 + (lane & 31) : tw0 + 4 * (lane & 7), hb = ROWMAP ? th0 + (lane >> 5) : th0 + (lane >> 3);
     const int xs4 = (int)(e.y & 0xffff), ymin = (int)(e.y >> 16), bw4 = (int)(e.x & 4095), bh = (int)((e.x >> 12) & 4095);
     const int pitch = bw4 * EPC;
 
@@ -640,7 +666,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
         float ix, iy;
-        e2b_xy(a, n, hb, w + k, ix, iy);
+        if (ROWMAP) e2b_xy(a, n, hb + 2 * k, w, ix, iy); else e2b_xy(a, n, hb, w + k, ix, iy);
         const float fx = floorf(ix), fy = floorf(iy);
         const int x0 = (int)fx, y0 = (int)fy;
         const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
@@ -662,7 +688,8 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
     const int plane = a.ph * a.pw;
     const size_t img_plane = (size_t)H * W;
     const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
-    T* out = (T*)a.pers + (size_t)n * a.C * plane + (size_t)hb * a.pw + w;
+    // ROWMAP: after the quad transpose lane l holds row hb + 2 (l % 4), columns 4 ((l % 32) / 4) .. +3 of the tile
+    T* out = (T*)a.pers + (size_t)n * a.C * plane + (ROWMAP ? (size_t)(hb + 2 * (lane & 3)) * a.pw + tw0 + 4 * ((lane & 31) >> 2) : (size_t)hb * a.pw + w);
     const int planes = a.B * a.C;
 
     if (fb_block) {
@@ -680,6 +707,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
                 const float v10 = Store<T>::ld(img + g1), v11 = Store<T>::ld(img + g1 + 1);
                 r[k] = e2p_blend(v00, v01, v10, v11, w00[k], w01[k], w10[k], w11[k]);
             }
+            if (ROWMAP) e2b_quad_transpose(r, lane);
             E2BStore4<T>::st(dstb + (size_t)c * plane, r);
         }
         return;
@@ -723,6 +751,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
                 E2BPair<T>::ld(box, r1[k], b0, b1);
                 r[k] = e2p_blend(a0, a1, b0, b1, w00[k], w01[k], w10[k], w11[k]);
             }
+            if (ROWMAP) e2b_quad_transpose(r, lane);
             if (!OMNI_DBG(a, 1)) E2BStore4<T>::st(dst, r);
             dst += plane;
             if (++cc == a.C) { cc = 0; dst += bskip; }
@@ -969,7 +998,7 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
         if (hipMalloc((void**)&tt.ent, sizeof(uint2) * (size_t)ntiles) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_e2p_build_boxes: out of memory"); }
         (void)hipMemsetAsync(dstats, 0, 2 * sizeof(int), stream);
         const unsigned nb = (unsigned)((ntiles + 3) / 4);
-        hipLaunchKernelGGL(e2b_tiles_kernel, dim3(nb), dim3(256), 0, stream, a, tt.ent, tt.tx, tt.tx * tt.ty, (int)ntiles, epc, cap_kb * 64, dstats);
+        hipLaunchKernelGGL(e2b_tiles_kernel, dim3(nb), dim3(256), 0, stream, a, tt.ent, tt.tx, tt.tx * tt.ty, (int)ntiles, epc, cap_kb * 64, e /* odd pitch: fp16 */, dstats);
         std::vector<int> hs((size_t)(2 + ntiles));
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs.data(), dstats, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_e2p_build_boxes: kernel failed"); }
@@ -1021,7 +1050,7 @@ int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, size_t tensor
     const auto& tt = g->e2p_boxes[sizeof(T) == 2 ? 1 : 0];
     const int slot_chunks = (tt.max_chunks + 63) / 64 * 64;
     const int nfb_blocks = tt.nfb * B, lds_start = (nfb_blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((e2p_box_kernel<T, NB>), dim3(lds_start + tt.norder), dim3(64), (size_t)NB * slot_chunks * 16, stream, a,
+    hipLaunchKernelGGL((e2p_box_kernel<T, NB, sizeof(T) == 2>), dim3(lds_start + tt.norder), dim3(64), (size_t)NB * slot_chunks * 16, stream, a,
                        (const uint2*)tt.ent, tt.tx, tt.tx * tt.ty, (const int*)tt.fb, nfb_blocks, (const int*)tt.order, lds_start,
                        slot_chunks, (unsigned)tensor_bytes);
     OMNI_HIP(hipGetLastError());

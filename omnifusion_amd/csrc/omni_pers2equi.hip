@@ -304,8 +304,9 @@ __global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __rest
             ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
         }
         if (xmax < 0) continue;                                   // wave-uniform: patch n covers no pixel of this tile
-        const int xa = xmin / epc * epc;
-        const int bw4 = (xmax / epc * epc + epc - xa) / epc, bh = ymax - ymin + 1;
+        int xa = xmin / epc * epc;
+        int bw4 = (xmax / epc * epc + epc - xa) / epc;
+        const int bh = ymax - ymin + 1;
         const bool fits = bw4 < 1024 && bh < 1024 && xa < 65536 && ymin < 65536 && bw4 * bh <= P2E_MAX_CHUNKS;
         maxch = max(maxch, fits ? bw4 * bh : P2E_MAX_CHUNKS + 1);
         if (lane == 0 && cnt < P2E_MAXC && fits)

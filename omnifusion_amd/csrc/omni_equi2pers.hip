@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
 // tile) are listed per geometry and handled by extra blocks of the same launch with direct gathers, one per (tile, batch item).
 constexpr int E2B_NPX = 4;                      // samples per lane
 constexpr int E2B_NJMAX = 8;                    // 1-KiB DMA pieces per box at most
+constexpr int E2B_RING_KB = 12;                 // LDS ring per wave (13 waves per CU by LDS; NJ <= 3: 4 slots, <= 6: 2 slots, else 1)
 
 typedef __amdgpu_buffer_rsrc_t e2b_rsrc_t;
 typedef __attribute__((address_space(3))) void* e2b_lptr_t;
@@ -627,10 +628,10 @@ template <> struct E2BStore4<__half> {
     { __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]); uint2 v; v.x = *reinterpret_cast<unsigned*>(&lo); v.y = *reinterpret_cast<unsigned*>(&hi); *reinterpret_cast<uint2*>(p) = v; }
 };
 
-template <typename T, int NB, bool ROWMAP>
+template <typename T, int NBMAX, bool ROWMAP>
 __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_pp,
                                                         const int* __restrict__ fb, int nfb_blocks, const int* __restrict__ order, int lds_start,
-                                                        int slot_chunks, unsigned tensor_bytes)
+                                                        unsigned tensor_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char e2b_smem[];        // the ONLY LDS object of this kernel
     constexpr int EPC = 16 / (int)sizeof(T), NPX = E2B_NPX;
@@ -713,13 +714,17 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
         return;
     }
     // every ordinary load has been consumed (the taps depend on them): nothing but LDS-DMA pieces and stores below
-    const unsigned slot_bytes = (unsigned)slot_chunks * 16u;
     const e2b_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.erp), (short)0, (int)tensor_bytes, 0x00020000);
     const unsigned rowb = (unsigned)W * (unsigned)sizeof(T), planeb = (unsigned)img_plane * (unsigned)sizeof(T);
     const int nchunk = bw4 * bh, njj = (nchunk + 63) >> 6;
     const size_t bskip = out_bstride - (size_t)a.C * plane;
 
     auto run = [&]<int NJ>(std::integral_constant<int, NJ>) {
+        // ring of E2B_RING_KB 1-KiB pieces per wave: a box of NJ pieces gets NB = min(NBMAX, largest power of two <= RING / NJ) slots of
+        // exactly NJ KiB — small boxes (the common case) keep 4 stages in flight, the rare large ones 2 or 1, in the same LDS footprint
+        constexpr int NBR = E2B_RING_KB / NJ >= 4 ? 4 : E2B_RING_KB / NJ >= 2 ? 2 : 1;
+        constexpr int NB = NBR < NBMAX ? NBR : NBMAX;
+        constexpr unsigned slot_bytes = NJ * 1024u;
         unsigned g[NJ];                                             // byte offset of my chunk of piece q inside an image plane
         {
             const float rbw = __builtin_amdgcn_rcpf((float)bw4);
@@ -1044,15 +1049,16 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
 }
 
 namespace {
-template <typename T, int NB>
+template <typename T, int NBMAX>
 int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, size_t tensor_bytes, hipStream_t stream)
 {
     const auto& tt = g->e2p_boxes[sizeof(T) == 2 ? 1 : 0];
-    const int slot_chunks = (tt.max_chunks + 63) / 64 * 64;
     const int nfb_blocks = tt.nfb * B, lds_start = (nfb_blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((e2p_box_kernel<T, NB, sizeof(T) == 2>), dim3(lds_start + tt.norder), dim3(64), (size_t)NB * slot_chunks * 16, stream, a,
+    const int njmax = (tt.max_chunks + 63) / 64;
+    const size_t lds = (size_t)(njmax > E2B_RING_KB ? njmax : E2B_RING_KB) * 1024;
+    hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2>), dim3(lds_start + tt.norder), dim3(64), lds, stream, a,
                        (const uint2*)tt.ent, tt.tx, tt.tx * tt.ty, (const int*)tt.fb, nfb_blocks, (const int*)tt.order, lds_start,
-                       slot_chunks, (unsigned)tensor_bytes);
+                       (unsigned)tensor_bytes);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
@@ -1060,9 +1066,10 @@ int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, size_t tensor
 template <typename T>
 int launch_e2b(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t tensor_bytes, hipStream_t stream)
 {
+    // stages in flight: 1, 2 or 4 (option e2p_nbuf), a divisor of the plane count (the stage loop runs in groups of NB)
     const int planes = B * C;
     int nb = omni_options().e2p_nbuf;
-    if (nb <= 0) nb = 2;
+    if (nb <= 0) nb = 2;                               // (4 stages in flight measured slower: 41.5 vs 38.3 us at B = 8, 18 x 256^2)
     if (nb >= 4 && planes % 4 == 0) return launch_e2b_nb<T, 4>(a, g, B, tensor_bytes, stream);
     if (nb >= 2 && planes % 2 == 0) return launch_e2b_nb<T, 2>(a, g, B, tensor_bytes, stream);
     return launch_e2b_nb<T, 1>(a, g, B, tensor_bytes, stream);

@@ -100,3 +100,61 @@ extern "C" int omni_debug_dma_rate(const float* src, unsigned bytes, int iters, 
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
+
+// MFMA issue patterns: cycles per v_mfma_f32_32x32x16_f16 for different accumulator dependency patterns, one wave per SIMD
+// (waves per block = 4 * wps).  pattern 0: one chain; 1: acc1, acc, acc1 (the f16x3 step); 2: two f16x3 tiles interleaved;
+// 3: four independent chains; 4: acc, acc1, acc1 (dependent pair adjacent)
+namespace {
+typedef float dbg_f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 dbg_h8v __attribute__((ext_vector_type(8)));
+template <int PAT>
+__global__ __launch_bounds__(512) void mfma_pattern_kernel(int iters, long long* cycles, float* sink)
+{
+    dbg_h8v x = (dbg_h8v)((_Float16)(threadIdx.x * 0.001f)), y = (dbg_h8v)((_Float16)(threadIdx.x * 0.002f));
+    dbg_f16v a0 = (dbg_f16v)(0.f), a1 = a0, a2 = a0, a3 = a0;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            if (PAT == 0) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0); a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a0, 0, 0, 0);
+            } else if (PAT == 1) {
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a1, 0, 0, 0); a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a1, 0, 0, 0);
+            } else if (PAT == 2) {
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a1, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a3, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a0, 0, 0, 0); a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a2, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a1, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a3, 0, 0, 0);
+            } else if (PAT == 3) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, y, a3, 0, 0, 0);
+            } else {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a1, 0, 0, 0);
+            }
+        }
+    }
+    const long long t1 = clock64();
+    float r = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r += a0[e] + a1[e] + a2[e] + a3[e];
+    if (r == 123.456f) sink[0] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
+}
+}  // namespace
+
+// returns in cycles[0] the s_memtime ticks of block 0's loop; MFMAs per wave = iters * 6 * (3 | 6 | 4 by pattern)
+extern "C" int omni_debug_mfma_pattern(int pattern, int iters, int blocks, int threads, long long* cycles, float* sink, omni_stream_t stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    switch (pattern) {
+    case 0: hipLaunchKernelGGL(mfma_pattern_kernel<0>, dim3(blocks), dim3(threads), 0, s, iters, cycles, sink); break;
+    case 1: hipLaunchKernelGGL(mfma_pattern_kernel<1>, dim3(blocks), dim3(threads), 0, s, iters, cycles, sink); break;
+    case 2: hipLaunchKernelGGL(mfma_pattern_kernel<2>, dim3(blocks), dim3(threads), 0, s, iters, cycles, sink); break;
+    case 3: hipLaunchKernelGGL(mfma_pattern_kernel<3>, dim3(blocks), dim3(threads), 0, s, iters, cycles, sink); break;
+    default: hipLaunchKernelGGL(mfma_pattern_kernel<4>, dim3(blocks), dim3(threads), 0, s, iters, cycles, sink); break;
+    }
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

@@ -55,6 +55,18 @@ OmniOptions& omni_options()
     return o;
 }
 
+int omni_num_cus()
+{
+    static int cus[64] = {0};                         // per device; a repeated query writes the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
 extern "C" int omni_set_option(const char* name, int value)
 {
     if (!name) OMNI_FAIL(OMNI_ERR_INVALID, "omni_set_option: null name");

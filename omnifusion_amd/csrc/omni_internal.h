@@ -39,6 +39,7 @@ struct OmniOptions {
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
 OmniOptions& omni_options();
+int omni_num_cus();                // compute units of the current device (cached per device)
 
 // Ablation bits that change RESULTS (skip the epilogue, suppress loads ...) exist only in the debug build of the library
 // (python -m omnifusion_amd.build --debug -> libomnifusion_hip_dbg.so, -DOMNI_DEBUG_BUILD); the product never carries them.

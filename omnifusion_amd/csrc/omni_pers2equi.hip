@@ -370,12 +370,23 @@ template <int N> __device__ __forceinline__ void p2e_wait_vm()
 // flight.  The tile is small (4 x 32 pixels, 2 per lane) so that a launch of BASELINE size still has >= 16 waves per CU to
 // hide each other's latencies: with one big tile per wave the launch is a handful of long dependent instruction chains per SIMD
 // (measured: 8 x 32 tiles, 24 us at B = 8 whatever the ring depth).
-template <typename T, int PL, bool CONF, int NB>
+// ring of P2E_RING_KB 1-KiB pieces per wave: a stage of `pieces` pieces (NJ, x2 for the fused confidence blend) gets the largest power
+// of two <= RING / pieces slots (at most nbmax, at most PL — PL % NB == 0 keeps a stage's slot a compile-time constant), each of
+// exactly `pieces` KiB: small boxes (the common case) keep 4 stages in flight, the rare large ones 2 or 1, in one LDS footprint
+constexpr int P2E_RING_KB = 10;
+constexpr int p2e_slots(int pieces, int nbmax, int pl)
+{
+    int nb = P2E_RING_KB / pieces >= 4 ? 4 : P2E_RING_KB / pieces >= 2 ? 2 : 1;
+    if (nb > nbmax) nb = nbmax;
+    while (nb > pl) nb >>= 1;
+    return nb;
+}
+
+template <typename T, int PL, bool CONF, int NBMAX>
 __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_y,
-                                                        int slot_chunks, unsigned tensor_bytes)
+                                                        unsigned tensor_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char p2e_smem[];        // the ONLY LDS object of this kernel
-    static_assert(PL % NB == 0 && NB >= 1, "slot index must be static");
     constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = P2E_NPX;
     const int lane = threadIdx.x;
     int ti, tj;
@@ -385,7 +396,6 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     const int j = tj * P2E_TW + col;
     const bool jin = j < a.W;
     const int p_begin = (int)blockIdx.y * PL;
-    const unsigned slot_bytes = (unsigned)slot_chunks * 16u * (unsigned)M;
     unsigned char* const ring = p2e_smem;
     const p2e_rsrc_t rs1 = p2e_make_rsrc(a.pers, tensor_bytes);
     const p2e_rsrc_t rs2 = p2e_make_rsrc(CONF ? a.pers2 : a.pers, tensor_bytes);
@@ -427,6 +437,8 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
         unsigned g[P2E_NJMAX];                                      // byte offset of my chunk of piece q, from the box origin
         // ---- (1) fill the ring: stages 0..NB-1
         auto prologue = [&]<int NJ>(std::integral_constant<int, NJ>) {
+            constexpr int NB = p2e_slots(NJ * M, NBMAX, PL);
+            constexpr unsigned slot_bytes = NJ * M * 1024u;
             const float rbw = __builtin_amdgcn_rcpf((float)bw4);
 #pragma unroll
             for (int q = 0; q < NJ; ++q) {
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
 #pragma unroll
                 for (int q = 0; q < NJ; ++q) {
                     p2e_dma16(rs1, dst + q * 1024, g[q], so);
-                    if (CONF) p2e_dma16(rs2, dst + (unsigned)slot_chunks * 16u + q * 1024, g[q], so);
+                    if (CONF) p2e_dma16(rs2, dst + NJ * 1024u + q * 1024, g[q], so);
                 }
             }
         };
@@ -480,6 +492,8 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
         }
         // ---- (3) the PL stages, instantiated on the number of DMA pieces per box
         auto stages = [&]<int NJ>(std::integral_constant<int, NJ>) {
+            constexpr int NB = p2e_slots(NJ * M, NBMAX, PL);
+            constexpr unsigned slot_bytes = NJ * M * 1024u;
             auto stage = [&]<int P>(std::integral_constant<int, P>) {
                 constexpr int SLOT = P % NB;
                 constexpr int K1 = (NB - 1 < PL - 1 - P) ? NB - 1 : PL - 1 - P;
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
                     // taps (y0,x0) (y1,x0) (y0,x1) (y1,x1) in the gather kernel's order of operations
                     acc[P][k] += fmaf(by, wd[k], fmaf(ay, wc[k], fmaf(bx, wb[k], ax * wa[k])));
                     if constexpr (CONF) {
-                        const unsigned char* box2 = box + (unsigned)slot_chunks * 16u;
+                        const unsigned char* box2 = box + NJ * 1024u;
                         LdsPair<T>::ld(box2, r0[k], ax, ay);
                         LdsPair<T>::ld(box2, r1[k], bx, by);
                         acc2[P][k] += fmaf(by, wd[k], fmaf(ay, wc[k], fmaf(bx, wb[k], ax * wa[k])));
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
 #pragma unroll
                     for (int q = 0; q < NJ; ++q) {
                         p2e_dma16(rs1, dst + q * 1024, g[q], so);
-                        if (CONF) p2e_dma16(rs2, dst + (unsigned)slot_chunks * 16u + q * 1024, g[q], so);
+                        if (CONF) p2e_dma16(rs2, dst + NJ * 1024u + q * 1024, g[q], so);
                     }
                 }
             };
@@ -630,17 +644,16 @@ void launch_p2e_pl(const P2EArgs& a, int planes, int rows4, int nblocks, hipStre
     else                  hipLaunchKernelGGL((p2e_kernel<T, 8, CONF, XS1>), dim3(nblocks), dim3(256), 0, stream, a, rows4, nblocks);
 }
 
-// ---- LDS path: launch geometry.  One wave per (tile, group of PL planes); ring = NB slots of the geometry's largest box (x2
-// for the fused confidence blend: both tensors' boxes travel together).  NB: 4 while the ring stays <= 16 KiB per wave (>= 10
-// waves per CU by LDS), else 2; option "p2e_nbuf" overrides (tuning).
-template <typename T, int PL, bool CONF, int NB>
+// ---- LDS path: launch geometry.  One wave per (tile, group of PL planes); LDS per wave = the ring (or the largest stage of the
+// geometry if that is larger); option "p2e_nbuf" caps the stages in flight (tuning).
+template <typename T, int PL, bool CONF, int NBMAX>
 int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
 {
     const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
-    const int slot_chunks = (tt.max_chunks + 63) / 64 * 64;
-    const size_t lds = (size_t)NB * slot_chunks * 16 * (CONF ? 2 : 1);
-    hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NB>), dim3(omni_xcd_rows_grid(g->p2e_ty, g->p2e_tx), planes / PL), dim3(64), lds, stream, a,
-                       (const uint2*)tt.ent, g->p2e_tx, g->p2e_ty, slot_chunks, (unsigned)tensor_bytes);
+    const int stage_kb = (tt.max_chunks + 63) / 64 * (CONF ? 2 : 1);
+    const size_t lds = (size_t)(stage_kb > P2E_RING_KB ? stage_kb : P2E_RING_KB) * 1024;
+    hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NBMAX>), dim3(omni_xcd_rows_grid(g->p2e_ty, g->p2e_tx), planes / PL), dim3(64), lds, stream, a,
+                       (const uint2*)tt.ent, g->p2e_tx, g->p2e_ty, (unsigned)tensor_bytes);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
@@ -648,20 +661,11 @@ int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int planes, size
 template <typename T, int PL, bool CONF>
 int launch_p2e_lds_pl(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
 {
-    const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
-    const int slot_bytes = (tt.max_chunks + 63) / 64 * 64 * 16 * (CONF ? 2 : 1);
     int nb = omni_options().p2e_nbuf;
-    if (nb <= 0) nb = 4 * slot_bytes <= 10240 ? 4 : 2;                // ring <= 10 KiB per wave: 16 waves per CU by LDS
-    if constexpr (PL >= 4) {
-        if (nb >= 4) return launch_p2e_lds_nb<T, PL, CONF, 4>(a, g, planes, tensor_bytes, stream);
-        if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, planes, tensor_bytes, stream);
-        return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
-    } else if constexpr (PL == 2) {
-        if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, planes, tensor_bytes, stream);
-        return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
-    } else {
-        return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
-    }
+    if (nb <= 0) nb = 2;   // measured: 2 stages x 16 waves/CU beat 4 stages (18.4 vs 19.3 us at B=8 18x256^2)
+    if (nb >= 4) return launch_p2e_lds_nb<T, PL, CONF, 4>(a, g, planes, tensor_bytes, stream);
+    if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, planes, tensor_bytes, stream);
+    return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
 }
 
 template <typename T, bool CONF>

@@ -287,8 +287,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);
+                    if (!OMNI_DBG(a, 16)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);   // precision map: weight-lo term
+                    if (!OMNI_DBG(a, 32)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);   // ... activation-lo term
                 }
             if (kc == 0) {                                       // stage ks+NST-1, issued under the first half's matrix work
                 __builtin_amdgcn_sched_barrier(0);
@@ -449,8 +449,8 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
                         const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
                         const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
-                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
-                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
+                        if (!OMNI_DBG(a, 16)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
+                        if (!OMNI_DBG(a, 32)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
                     }
                 }
             }

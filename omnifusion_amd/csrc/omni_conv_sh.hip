@@ -71,6 +71,13 @@ template <int N> __device__ __forceinline__ void wait_vm()
 #undef OMNI_VM
 }
 
+// Every LDS read this wave has issued has returned.  REQUIRED in front of a barrier that licenses another wave to overwrite the
+// buffer those reads came from: hipcc sinks the MFMAs that consume a stage's last fragments (and the s_waitcnt lgkmcnt that guards
+// them) BELOW the following s_barrier, so without this wait a wave can pass the barrier with ds_reads still queued and a faster
+// wave's LDS-DMA for the next stage then lands in the buffer first.  Measured: one wrong output row in 1 of 600 forwards at 8
+// panoramas on two streams (1 of 30 at 16) with the 4-wave halo kernel, none in 3000 with the wait (tools/lanes_trace.py).
+__device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 struct ShConvArgs {
     const void* src1; const void* src2;      // SH activations [M,H,W,C1], [M,H,W,C2] (src2 may be null)
     const void* wt;                          // halfs [Cout][KH*KW*(C1+C2)/32][hi32|lo32], BN folded
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         // a smaller count only waits longer, 0 is always safe)
         if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
         else                       wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                            // ... everybody's have; everybody is done reading stage ks-1
+        wait_lds_reads();                                        // my fragment reads of stage ks-1 have returned ...
+        __builtin_amdgcn_s_barrier();                            // ... everybody's pieces have landed; everybody is done reading stage ks-1
         asm volatile("" ::: "memory");
         const unsigned char* sl = lds + SLOT * STAGE;
         h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
@@ -286,7 +294,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
+                    if (!OMNI_DBG(a, 64)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
+                    else { acc[i][j][0] += (float)bh[kc][j][0] * (float)ah[kc][i][0]; }
                     if (!OMNI_DBG(a, 16)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);   // precision map: weight-lo term
                     if (!OMNI_DBG(a, 32)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);   // ... activation-lo term
                 }
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             wait_vm<0>();                                         // halo (ky == 0) and this kernel row's weights have landed
+            wait_lds_reads();                                     // ... and my reads of the other weight buffer have returned
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (ky < 2) issue_b(g, ky + 1, buf ^ 1);              // next weights under this row's matrix work
@@ -457,6 +467,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
             buf ^= 1;
         }
         if (g + 1 < G) {                                          // everybody is done with this group's halo: fetch the next
+            wait_lds_reads();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue_a(g + 1);

@@ -158,3 +158,94 @@ extern "C" int omni_debug_mfma_pattern(int pattern, int iters, int blocks, int t
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
+
+// Which instruction class of a victim kernel returns wrong values while a convolution runs on another stream?
+// mode 0: per-lane 8-byte loads from a small hot table; 1: + v_rcp_f32 / Newton arithmetic on them; 2: wave-uniform scalar loads of
+// a big by-value kernel argument (PatchTab); 3: the same values through a pointer (vector loads)
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256) void victim_kernel(const float2* __restrict__ tab, int tabn, PatchTab pt, const float* __restrict__ ptv,
+                                                     float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 t = tab[i % tabn];
+    float r = 0.f;
+    if (MODE == 0) r = t.x + 2.0f * t.y;
+    if (MODE == 1) {
+        const float c = 1.0f + t.x * t.y;
+        float rc = __builtin_amdgcn_rcpf(c);
+        rc = fmaf(fmaf(-c, rc, 1.0f), rc, rc);
+        r = floorf(rc * 1000.0f) + rc;
+    }
+    if (MODE == 2) {
+        // long version: wave-uniform data-dependent patch index (like pers2equi's candidate loop), many trips
+        unsigned long long m = 0x3ffffull;
+        for (int rep = 0; rep < 40; ++rep) {
+            unsigned long long mm = m;
+            while (mm) {
+                const int k = __builtin_ctzll(mm); mm &= mm - 1;
+                const float cd = t.x * pt.clam[k] + t.y * pt.slam[k], sd = t.y * pt.clam[k] - t.x * pt.slam[k];
+                const float cc = pt.sphi[k] * 0.3f + pt.cphi[k] * 0.9f * cd + 2.0f;
+                float rc = __builtin_amdgcn_rcpf(cc);
+                rc = fmaf(fmaf(-cc, rc, 1.0f), rc, rc);
+                const float X = (0.9f * sd * rc + 1.0f) * 64.0f, Y = ((pt.cphi[k] * 0.3f - pt.sphi[k] * 0.9f * cd) * rc + 1.0f) * 64.0f;
+                const float fx = floorf(X), fy = floorf(Y);
+                r += (fx + 1.0f - X) * (fy + 1.0f - Y) + (X - fx) * (Y - fy) * 0.5f;
+            }
+            m = (m >> 1) | ((m & 1ull) << 17);
+        }
+    }
+    if (MODE == 3) {
+        // packed fp32 math (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): the form hipcc's SLP vectoriser gives adjacent f32 products
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 acc = {0.0f, 0.0f};
+        for (int rep = 0; rep < 400; ++rep) {
+            const float X = t.x * 127.0f + (float)rep * 0.37f, Y = t.y * 127.0f + (float)rep * 0.11f;
+            const float fx = floorf(X), fy = floorf(Y);
+            const f2 ax = {fx + 1.0f - X, X - fx}, ay = {fy + 1.0f - Y, Y - fy};
+            const f2 w0 = ax * ay.x, w1 = ax * ay.y;            // v_pk_mul_f32
+            acc += w0 + w1 * 0.5f;                                // v_pk_fma / v_pk_add
+        }
+        r = acc.x + acc.y;
+    }
+    if (MODE == 4) {
+        // the same arithmetic, one f32 at a time (asm barriers keep the SLP vectoriser out)
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int rep = 0; rep < 400; ++rep) {
+            const float X = t.x * 127.0f + (float)rep * 0.37f, Y = t.y * 127.0f + (float)rep * 0.11f;
+            const float fx = floorf(X), fy = floorf(Y);
+            float ax0 = fx + 1.0f - X, ax1 = X - fx, ay0 = fy + 1.0f - Y, ay1 = Y - fy;
+            float w00 = ax0 * ay0; asm volatile("" : "+v"(w00));
+            float w01 = ax1 * ay0; asm volatile("" : "+v"(w01));
+            float w10 = ax0 * ay1; asm volatile("" : "+v"(w10));
+            float w11 = ax1 * ay1; asm volatile("" : "+v"(w11));
+            a0 += w00 + w10 * 0.5f; asm volatile("" : "+v"(a0));
+            a1 += w01 + w11 * 0.5f; asm volatile("" : "+v"(a1));
+        }
+        r = a0 + a1;
+    }
+    out[i] = r;
+}
+}  // namespace
+
+extern "C" int omni_debug_victim(int mode, const float* tab, int tabn, const float* ptv, float* out, int n, omni_stream_t stream)
+{
+    PatchTab pt;
+    pt.N = 18;
+    for (int k = 0; k < OMNI_MAX_PATCH; ++k) {
+        pt.lam0[k] = 0.1f * k; pt.slam[k] = sinf(0.37f * k); pt.clam[k] = cosf(0.37f * k); pt.sphi[k] = sinf(0.11f * k); pt.cphi[k] = cosf(0.11f * k);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((n + 255) / 256), b(256);
+    const float2* t2 = (const float2*)tab;
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(victim_kernel<0>, g, b, 0, s, t2, tabn, pt, ptv, out, n); break;
+    case 1: hipLaunchKernelGGL(victim_kernel<1>, g, b, 0, s, t2, tabn, pt, ptv, out, n); break;
+    case 2: hipLaunchKernelGGL(victim_kernel<2>, g, b, 0, s, t2, tabn, pt, ptv, out, n); break;
+    case 3: hipLaunchKernelGGL(victim_kernel<3>, g, b, 0, s, t2, tabn, pt, ptv, out, n); break;
+    default: hipLaunchKernelGGL(victim_kernel<4>, g, b, 0, s, t2, tabn, pt, ptv, out, n); break;
+    }
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

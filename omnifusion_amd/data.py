@@ -65,24 +65,37 @@ def preprocess_depth(frames_u16, size, min_depth=0.1, max_depth=8.0):
 class DeviceFeeder:
     """Pinned, multi-buffered host -> device staging of decoded frames on a copy stream; /255 + HWC->CHW on the consumer's stream.
 
-    The yielded tensor is ONE reusable float32 buffer: it is valid until the next batch is requested (stream order on the
+    The yielded tensor is a reusable float32 buffer: it is valid until the next batch is requested (stream order on the
     consumer's current stream guarantees that the previous forward has read it before it is overwritten) — clone it to keep it.
     Device footprint: `depth` uint8 frames + one float32 batch (the 256 MB Infinity Cache also holds the network's weights and
-    activations: a float32 buffer per slot measurably slows the forward down)."""
+    activations: a float32 buffer per slot measurably slows the forward down).
 
-    def __init__(self, batches, size, device=None, depth=3):
+    A consumer that reads the batch on ANOTHER stream (`spherical_fusion.pipelined`) asks for `out_buffers` = forwards in flight
+    + 1 and reports when it is done with a batch: `feeder.done_with(rgb, pending.event)` — the buffer is rewritten only after
+    that event."""
+
+    def __init__(self, batches, size, device=None, depth=3, out_buffers=1):
         self.batches, self.size, self.depth = batches, _hw(size), max(2, int(depth))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
         self._slots = None
-        self._out = None
+        self._outs, self._done, self._k, self._nout = None, None, 0, max(1, int(out_buffers))
+
+    def done_with(self, rgb, event):
+        """`rgb` (a tensor this feeder yielded) is read by work on another stream that `event` marks the end of"""
+        for j, o in enumerate(self._outs):
+            if o.data_ptr() == rgb.data_ptr():
+                self._done[j] = event
+                return
+        raise ValueError("not a batch of this feeder")
 
     def _alloc(self, shape):
         B, Hs, Ws, _ = shape
         H, W = self.size
         self._slots = [{"pin": None, "dev": torch.empty(shape, dtype=torch.uint8, device=self.device),
                         "ready": torch.cuda.Event(), "free": None} for _ in range(self.depth)]
-        self._out = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
+        self._outs = [torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device) for _ in range(self._nout)]
+        self._done = [None] * self._nout
 
     def _stage(self, slot, frames):
         s = self._slots[slot]
@@ -128,6 +141,11 @@ class DeviceFeeder:
         s = self._slots[slot]
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(s["ready"])                                     # no host synchronisation
-        preprocess_rgb(s["dev"], self.size, out=self._out)             # 35 us at 8 x 512x1024; behind the previous forward in stream order
+        j = self._k % self._nout
+        self._k += 1
+        if self._done[j] is not None:
+            cur.wait_event(self._done[j])                              # a consumer on another stream has finished with this buffer
+            self._done[j] = None
+        preprocess_rgb(s["dev"], self.size, out=self._outs[j])         # 35 us at 8 x 512x1024; behind the previous forward in stream order
         ev = torch.cuda.Event(); ev.record(cur); s["free"] = ev        # the slot's device frame may be overwritten after this point
-        return self._out
+        return self._outs[j]

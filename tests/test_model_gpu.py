@@ -459,3 +459,81 @@ def test_geometry_cache_is_bounded():
     finally:
         L.set_option("geom_cache_max", 16)
         lib.omni_geometry_cache_clear()
+
+
+def test_pipelined_forwards_give_the_bits_of_plain_calls():
+    """`net.pipelined(depth)`: several complete forwards in flight on several streams (private execution contexts) — same bits
+    as one call after the other, also for the iterative model and across a weight reload"""
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    batches = [torch.rand((3, 3, 128, 256), generator=torch.Generator().manual_seed(20 + k)).to(DEV) for k in range(5)]
+    ref = [net(b, confidence=True).clone() for b in batches]
+    for depth in (1, 2, 3):
+        run = net.pipelined(depth)
+        pend = [run(b, confidence=True) for b in batches]
+        assert all(torch.equal(p.get(), r) for p, r in zip(pend, ref)), depth
+    net.load_state_dict(make_state_dict(7, 18, False))                    # the slots alias the packed weights: they must follow
+    new = net(batches[0], confidence=True).clone()
+    assert not torch.equal(new, ref[0])
+    assert torch.equal(run(batches[0], confidence=True).get(), new)
+    it = spherical_fusion_it(4, 18, (128, 128), (80, 80)).cuda()
+    it.load_state_dict(make_state_dict(42, 18, True))
+    want = [o.clone() for o in it(batches[1], iter=2)]
+    got = it.pipelined(2)(batches[1], iter=2).get()
+    assert len(got) == 2 and all(torch.equal(g, w) for g, w in zip(got, want))
+
+
+def test_kernels_are_correct_beside_another_streams_convolutions():
+    """Regression for two concurrency bugs found in round 2 (DESIGN 'Concurrency'): (1) the 4-wave halo convolution passed its
+    stage barrier with fragment reads still queued — one wrong output row in 1 of 600 two-stream forwards; (2) packed-fp32
+    instructions (hipcc's SLP form of adjacent f32 products) return wrong values while another wave of the CU issues dense
+    MFMAs — pers2equi beside a convolution was wrong in most launches.  Here: resample kernels and a two-lane network beside
+    MFMA-dense convolutions on a second stream, bit for bit against the quiet result."""
+    import ctypes
+    from omnifusion_amd import _lib as L
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi, pers2equi_conf
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    M, B, N, P = 144, 8, 18, 128
+    x = torch.randn(M, 64, 64, 32, device=DEV)
+    xs = torch.empty_like(x); lib.omni_sh_from_f32(P_(x), P_(xs), ctypes.c_size_t(x.numel()), L.stream_of(x))
+    w16 = split_weights_f16x3(torch.randn(32, 288) / 17.0).to(DEV); bias = torch.randn(32, device=DEV); cout = torch.empty(M, 64, 64, 32, device=DEV)
+
+    def noise():
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.omni_conv2d_sh_f16x3_ws(P_(xs), None, P_(w16), P_(bias), None, P_(cout), 1, M, 64, 64, 32, 0, 32, 3, 3, 1, 1, 1, 1, None, ctypes.c_size_t(0), st) == 0
+    lay = L.LAYOUT_BNCHW
+    a0 = torch.rand((B, N, 1, P, P), device=DEV); c0 = torch.rand((B, N, 1, P, P), device=DEV); rgb = torch.rand((B, 3, 512, 1024), device=DEV)
+    victims = {"pers2equi": lambda: pers2equi(a0, 80, 4, P, (512, 1024), None, layout=lay),
+               "pers2equi_conf": lambda: pers2equi_conf(a0, c0, 80, 4, P, (512, 1024), layout=lay),
+               "equi2pers": lambda: equi2pers_patches(rgb, 80, 4, P, layout=lay)}
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        for gather in (0, 1):
+            L.set_option("p2e_gather", gather); L.set_option("e2p_gather", gather)
+            for name, f in victims.items():
+                ref = f().clone()
+                torch.cuda.synchronize()
+                for rep in range(4):
+                    with torch.cuda.stream(s2):
+                        for _ in range(12): noise()
+                    with torch.cuda.stream(s1):
+                        outs = [f() for _ in range(8)]
+                    torch.cuda.synchronize()
+                    assert all(torch.equal(o, ref) for o in outs), (name, gather, rep)
+    finally:
+        L.set_option("p2e_gather", 0); L.set_option("e2p_gather", 0)
+    # the network on two half-batch lanes, many times, against one lane
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    try:
+        spherical_fusion.LANES = 1
+        one = net(rgb, confidence=True).clone()
+    finally:
+        spherical_fusion.LANES = 2
+    for rep in range(150):
+        assert torch.equal(net(rgb, confidence=True), one), rep

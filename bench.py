@@ -212,11 +212,11 @@ def main():
         pass
     torch.cuda.synchronize()
     tf = time.perf_counter()
-    feeder = DeviceFeeder((host_frames[k % 4] for k in range(nfeed)), (ERP_H, ERP_W), device=dev, out_buffers=depth + 1 if depth > 1 else 1)
+    feeder = DeviceFeeder((host_frames[k % 4] for k in range(nfeed)), (ERP_H, ERP_W), device=dev, out_buffers=2 if depth > 1 else 1)
     for frame_rgb in feeder:
         p_ = run(frame_rgb, confidence=True)
         if depth > 1:
-            feeder.done_with(frame_rgb, p_.event)                 # the forward reads the batch on its own stream
+            feeder.done_with(frame_rgb, p_.input_read)                 # the forward reads the batch on its own stream
         pending.append(p_)
         if len(pending) > depth:
             pending.popleft().get()

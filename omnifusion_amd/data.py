@@ -70,9 +70,9 @@ class DeviceFeeder:
     Device footprint: `depth` uint8 frames + one float32 batch (the 256 MB Infinity Cache also holds the network's weights and
     activations: a float32 buffer per slot measurably slows the forward down).
 
-    A consumer that reads the batch on ANOTHER stream (`spherical_fusion.pipelined`) asks for `out_buffers` = forwards in flight
-    + 1 and reports when it is done with a batch: `feeder.done_with(rgb, pending.event)` — the buffer is rewritten only after
-    that event."""
+    A consumer that reads the batch on ANOTHER stream (`spherical_fusion.pipelined`) asks for `out_buffers=2` and reports when the
+    batch has been read: `feeder.done_with(rgb, pending.input_read)` (the event after equi2pers, the forward's only reader of
+    the panoramas) — the buffer is rewritten only after that event."""
 
     def __init__(self, batches, size, device=None, depth=3, out_buffers=1):
         self.batches, self.size, self.depth = batches, _hw(size), max(2, int(depth))

@@ -50,13 +50,18 @@ def _build_tree(root, sch):
 
 class _Pending:
     """result of a pipelined forward: tensors that a side stream is still writing"""
-    def __init__(self, out, event, stream):
-        self._out, self._event, self._stream = out, event, stream
+    def __init__(self, out, event, stream, input_read=None):
+        self._out, self._event, self._stream, self._input_read = out, event, stream, input_read
 
     @property
     def event(self):
-        """recorded on the side stream after the forward: the input batch may be overwritten once it has completed"""
+        """recorded on the side stream after the forward"""
         return self._event
+
+    @property
+    def input_read(self):
+        """recorded right after equi2pers, the only reader of the input batch: the batch may be overwritten once it has completed"""
+        return self._input_read if self._input_read is not None else self._event
 
     def get(self):
         cur = torch.cuda.current_stream(self._stream.device)
@@ -117,21 +122,26 @@ class _Pipelined:
         main, had = net._eng, "LANES" in net.__dict__
         lanes = net.__dict__.get("LANES")
         net._eng, net.LANES = eng, 1                                       # whole batch per kernel; the overlap comes from the next batch
+        net._want_input_event, net._input_read = True, None
         try:
             with torch.cuda.stream(stream):
                 out = net.forward(rgb, *args, **kwargs)
                 event = stream.record_event()
+            input_read = net._input_read
         finally:
+            net._want_input_event, net._input_read = False, None
             net._eng = main
             if had:
                 net.LANES = lanes
             else:
                 del net.LANES
-        return _Pending(out, event, stream)
+        return _Pending(out, event, stream, input_read)
 
 
 class spherical_fusion(nn.Module):
     _ITERATIVE = False
+    _want_input_event = False     # pipelined(): record an event when the forward has finished reading its input batch
+    _input_read = None
     # Two halves of the batch on two streams.  Every layer of the network is ONE kernel whose last blocks leave most of the
     # chip idle (the deep layers are 2.25 blocks per CU at 8 panoramas); with two independent half-batch chains in flight
     # the scheduler fills one chain's tail with the other chain's blocks.  Results are bit-identical to the single-stream
@@ -241,6 +251,7 @@ class spherical_fusion(nn.Module):
         bs, _, H, W = rgb.shape
         with torch.cuda.device(rgb.device):
             patches = equi2pers_patches(rgb, self.fov, self.nrows, self.patch_size, layout=_lib.LAYOUT_BNCHW)   # :243
+            self._input_read = torch.cuda.current_stream(rgb.device).record_event() if self._want_input_event else None
             a, c = self.network(patches, bs, confidence)                                                        # :245-306
             return e.blend(a, c, (H, W))                                                                        # :307-313
 

@@ -30,6 +30,7 @@ class spherical_fusion(_single):
         p4 = (P // 4, P // 4)
         with torch.cuda.device(high_res.device):
             patches = equi2pers_patches(high_res, self.fov, self.nrows, self.patch_size, layout=_lib.LAYOUT_BNCHW)   # :315 (= :384)
+            self._input_read = torch.cuda.current_stream(high_res.device).record_event() if self._want_input_event else None
             xyz, _, _ = equi2pers_aux(high_res.device, self.fov, self.nrows, p4, want_xyz=True, want_uv=False)       # :316
             pf = e.mlp_points("mlp_points1", xyz, None, self.npatches)                                               # :319
             a, c = self.network(patches, bs, confidence, point_feat=pf)

@@ -18,6 +18,7 @@ deterministic random-init generator unless --checkpoint names a reference state_
 image over N ranks (omnifusion_amd/dist.py) and the meters are summed over ranks at the end.
 """
 import argparse
+import collections
 import math
 import os
 import sys
@@ -48,6 +49,7 @@ def main():
     ap.add_argument("--src-scale", type=int, default=1, help="decoded frames are this many times larger than the network input (INTER_AREA on the device)")
     ap.add_argument("--ply-every", type=int, default=0); ap.add_argument("--out", default="results")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--depth", type=int, default=3, help="forwards in flight (spherical_fusion.pipelined); 1 = the loop of test.py as written")
     args = ap.parse_args()
     from omnifusion_amd import dist
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -75,15 +77,30 @@ def main():
     meters = DepthMetrics()
     os.makedirs(args.out, exist_ok=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    feeder = DeviceFeeder((r for r, _ in frames), (args.height, args.width), device=dev)
+    depth = max(1, args.depth)
+    feeder = DeviceFeeder((r for r, _ in frames), (args.height, args.width), device=dev, out_buffers=2 if depth > 1 else 1)
+    run = network.pipelined(depth)
+
+    def finish(batch_idx, rgb, gt, pending):                                                                 # the part of the loop after the forward
+        depth_gt, mask = gt
+        out = pending.get()
+        out = out[-1] if args.iterative else out
+        if args.ply_every and batch_idx % args.ply_every == 0 and rank == 0:
+            write_ply_pointcloud(os.path.join(args.out, f"test_pred_{batch_idx}"), out, rgb)                 # test.py:233-238 (before the in-place scaling)
+        meters.update(out, depth_gt, mask.to(torch.float32))                                                 # test.py:203
+
+    inflight = collections.deque()
     for batch_idx, rgb in enumerate(feeder):
         d16 = torch.from_numpy(frames[batch_idx][1].view(np.int16)).to(dev, non_blocking=True)
-        depth, mask = preprocess_depth(d16, (args.height, args.width))                                       # loader :76-80,99-109
-        with torch.no_grad():
-            out = network(rgb, iter=args.iter)[-1] if args.iterative else network(rgb)                       # test.py:198-199
-            if args.ply_every and batch_idx % args.ply_every == 0 and rank == 0:
-                write_ply_pointcloud(os.path.join(args.out, f"test_pred_{batch_idx}"), out, rgb)             # test.py:233-238 (before the in-place scaling)
-            meters.update(out, depth, mask.to(torch.float32))                                                # test.py:203
+        gt = preprocess_depth(d16, (args.height, args.width))                                                # loader :76-80,99-109
+        pending = run(rgb, iter=args.iter) if args.iterative else run(rgb)                                   # test.py:198-199, `depth` batches in flight
+        feeder.done_with(rgb, pending.input_read) if depth > 1 else None
+        want_ply = args.ply_every and batch_idx % args.ply_every == 0 and rank == 0
+        inflight.append((batch_idx, rgb.clone() if (want_ply and depth > 1) else rgb, gt, pending))        # (the feeder recycles rgb once equi2pers has read it)
+        if len(inflight) >= depth:
+            finish(*inflight.popleft())
+    while inflight:
+        finish(*inflight.popleft())
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     avg = meters.averages() if world == 1 else meters.averages_all_ranks()
     if rank == 0:

@@ -103,25 +103,72 @@ def _concurrent_streams(n, device, candidates=12, spin=400_000):
 
 
 class _Pipelined:
-    def __init__(self, net, depth):
+    def __init__(self, net, depth, graphs=False):
         if depth < 1:
             raise ValueError("depth >= 1")
-        self.net, self.depth, self.k, self.slots, self.version = net, int(depth), 0, None, None
+        self.net, self.depth, self.graphs = net, int(depth), bool(graphs)
+        self.k, self.slots, self.version, self.captured = 0, None, None, {}
+
+    def _enter(self, eng):
+        net = self.net
+        state = (net._eng, "LANES" in net.__dict__, net.__dict__.get("LANES"))
+        net._eng, net.LANES = eng, 1                                       # whole batch per kernel; the overlap comes from the next batch
+        return state
+
+    def _leave(self, state):
+        net = self.net
+        net._eng = state[0]
+        if state[1]:
+            net.LANES = state[2]
+        else:
+            del net.LANES
+
+    def _capture(self, slot, eng, stream, rgb, args, kwargs):
+        """one hipGraph per (slot, input shape, arguments): the ~135 launches of a forward replay from ONE graph launch — below
+        ~4 panoramas per forward the host cannot enqueue them as fast as several streams execute them"""
+        net = self.net
+        static_in = rgb.clone()
+        state = self._enter(eng)
+        try:
+            stream.wait_stream(torch.cuda.current_stream(rgb.device))
+            with torch.cuda.stream(stream):
+                net.forward(static_in, *args, **kwargs)                    # warm-up on this slot: workspace, allocator pools
+            torch.cuda.synchronize(rgb.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                static_out = net.forward(static_in, *args, **kwargs)
+        finally:
+            self._leave(state)
+        return g, static_in, static_out
 
     def __call__(self, rgb, *args, **kwargs):
         net = self.net
         net._check(rgb)                                                    # (re)packs the weights if the master copy changed
         if self.slots is None or self.version != net._pack_version or self.slots[0][1].device != rgb.device:
             self.slots = [(net._eng.lane(), st) for st in _concurrent_streams(self.depth, rgb.device)]
-            self.version = net._pack_version
-        eng, stream = self.slots[self.k % self.depth]
+            self.version, self.captured = net._pack_version, {}
+        slot = self.k % self.depth
+        eng, stream = self.slots[slot]
         self.k += 1
         cur = torch.cuda.current_stream(rgb.device)
+        if self.graphs:
+            key = (slot, tuple(rgb.shape), args, tuple(sorted(kwargs.items())))
+            if key not in self.captured:
+                self.captured[key] = self._capture(slot, eng, stream, rgb, args, kwargs)
+            g, static_in, static_out = self.captured[key]
+            stream.wait_stream(cur)
+            rgb.record_stream(stream)
+            with torch.cuda.stream(stream):
+                static_in.copy_(rgb, non_blocking=True)
+                input_read = stream.record_event()                         # the caller's batch has been copied
+                g.replay()
+                # the graph's output buffers are rewritten by this slot's next replay: hand out copies
+                out = [t.clone() for t in static_out] if isinstance(static_out, (list, tuple)) else static_out.clone()
+                event = stream.record_event()
+            return _Pending(out, event, stream, input_read)
         stream.wait_stream(cur)                                            # the input was produced on the caller's stream
         rgb.record_stream(stream)
-        main, had = net._eng, "LANES" in net.__dict__
-        lanes = net.__dict__.get("LANES")
-        net._eng, net.LANES = eng, 1                                       # whole batch per kernel; the overlap comes from the next batch
+        state = self._enter(eng)
         net._want_input_event, net._input_read = True, None
         try:
             with torch.cuda.stream(stream):
@@ -130,11 +177,7 @@ class _Pipelined:
             input_read = net._input_read
         finally:
             net._want_input_event, net._input_read = False, None
-            net._eng = main
-            if had:
-                net.LANES = lanes
-            else:
-                del net.LANES
+            self._leave(state)
         return _Pending(out, event, stream, input_read)
 
 
@@ -229,14 +272,15 @@ class spherical_fusion(nn.Module):
         run.graph = g
         return run
 
-    def pipelined(self, depth=2):
+    def pipelined(self, depth=3, graphs=False):
         """Throughput mode for a STREAM of batches (test.py's loader loop, serving): `run = net.pipelined(2)`, then
         `pending = run(rgb)` enqueues a complete forward — equi2pers, network, blend — on stream k % depth with a private
         execution context and returns at once; `pending.get()` makes the current stream wait for it and returns the output.
         With two forwards in flight one batch's HBM-bound decoder runs beside the next batch's matrix-bound encoder and every
         kernel works on the whole batch (M = B*N patches) instead of a half-batch lane: +10 % panoramas/s at 8 per GPU.
-        Results are the bits of a plain call."""
-        return _Pipelined(self, depth)
+        Results are the bits of a plain call.  graphs=True replays one captured hipGraph per slot instead of enqueueing the ~135 launches
+        of a forward from Python: below ~4 panoramas per forward the host is the limit (one panorama per forward: 1170 -> see DESIGN 5b)."""
+        return _Pipelined(self, depth, graphs)
 
     def _check(self, rgb):
         if self.training:

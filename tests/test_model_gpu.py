@@ -469,10 +469,11 @@ def test_pipelined_forwards_give_the_bits_of_plain_calls():
     net.load_state_dict(make_state_dict(42, 18, False))
     batches = [torch.rand((3, 3, 128, 256), generator=torch.Generator().manual_seed(20 + k)).to(DEV) for k in range(5)]
     ref = [net(b, confidence=True).clone() for b in batches]
-    for depth in (1, 2, 3):
-        run = net.pipelined(depth)
-        pend = [run(b, confidence=True) for b in batches]
-        assert all(torch.equal(p.get(), r) for p, r in zip(pend, ref)), depth
+    for depth, graphs in ((1, False), (2, False), (3, False), (2, True), (3, True)):
+        run = net.pipelined(depth, graphs=graphs)
+        for rnd in range(2):                                              # (second round: every slot replays / is reused)
+            pend = [run(b, confidence=True) for b in batches]
+            assert all(torch.equal(p.get(), r) for p, r in zip(pend, ref)), (depth, graphs, rnd)
     net.load_state_dict(make_state_dict(7, 18, False))                    # the slots alias the packed weights: they must follow
     new = net(batches[0], confidence=True).clone()
     assert not torch.equal(new, ref[0])

@@ -1,5 +1,5 @@
 """Throughput of plain calls (two half-batch lanes) vs pipelined(depth) at B panoramas per forward; bit check.
-Environment: B (default 8), DEPTHS (default 1,2,3,4), INNER_LANES (half-batch lanes inside a pipelined forward, default 1)."""
+Environment: B (default 8), DEPTHS (default 1,2,3,4), GRAPHS=1 (one hipGraph per slot)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,7 +21,7 @@ def piped(run, n):
 plain(10); torch.cuda.synchronize(); t0 = time.perf_counter(); plain(40); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
 print("B=%d plain            : %.3f ms/forward %.0f pano/s" % (B, dt * 1e3, B / dt), flush=True)
 for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
-    run = net.pipelined(depth)
+    run = net.pipelined(depth, graphs=os.environ.get('GRAPHS', '0') == '1')
     outs = [run(b, confidence=True) for b in batches]
     same = all(torch.equal(o.get(), r) for o, r in zip(outs, ref))
     piped(run, 10); torch.cuda.synchronize(); t0 = time.perf_counter(); piped(run, 60); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 60

@@ -196,6 +196,20 @@ def main():
     torch.cuda.synchronize()
     r_e2p = float(np.mean([er[k][0].elapsed_time(er[k][1]) for k in range(K)])) * 1e-3
     r_p2e = float(np.mean([er[k][1].elapsed_time(er[k][2]) for k in range(K)])) * 1e-3
+    # ... and as consecutive pipelined forwards run them: equi2pers of one batch beside pers2equi of another (two streams that really
+    # run side by side, host wall clock over K pairs)
+    from omnifusion_amd.model.spherical_model import _concurrent_streams
+    sa, sb = _concurrent_streams(2, dev)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t_pair = time.perf_counter()
+        for k in range(4 * K):
+            with torch.cuda.stream(sa):
+                equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY)
+            with torch.cuda.stream(sb):
+                pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
+        torch.cuda.synchronize()
+        t_pair = (time.perf_counter() - t_pair) / (4 * K)
     bytes_e2p = B * 3 * (ERP_H * ERP_W + P * P * NPATCH) * 4          # SURVEY 8d algorithmic bytes
     bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * 4
     gbs_pair = (bytes_e2p + bytes_p2e) / (r_e2p + r_p2e) / 1e9
@@ -301,6 +315,10 @@ def main():
                               # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), written by tools/pmc_traffic.sh
                               # together with the hash of the sources it was measured on: null when that is not THIS build
                               "traffic": traffic, "traffic_note": traffic_note,
+                              "two_streams": {"us_per_pair": t_pair * 1e6, "GB/s": (bytes_e2p + bytes_p2e) / t_pair / 1e9,
+                                              "frac": (bytes_e2p + bytes_p2e) / t_pair / 1e9 / HBM_PEAK_GBS,
+                                              "note": "the two operators on two streams (as consecutive pipelined forwards run them); "
+                                                      "`achieved` / `frac` above are the strict figures: one launch after the other, HIP events per kernel"},
                               "equi2pers": {"us": r_e2p * 1e6, "bytes": bytes_e2p, "GB/s": bytes_e2p / r_e2p / 1e9},
                               "pers2equi": {"us": r_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / r_p2e / 1e9}},
     }

@@ -113,6 +113,9 @@ def main():
     from omnifusion_amd.model.spherical_model import spherical_fusion
     from omnifusion_amd.weights import make_state_dict
     _lib.load()
+    if world > 1:                                              # sharded runs reproduce single-GPU results bit for bit whatever the
+        from omnifusion_amd.model._engine import Engine       # per-rank batch (SURVEY 8d parity gate): one split-K plan for all sizes
+        Engine.latency_plan = False
 
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)

@@ -67,6 +67,9 @@ def main():
     else:
         from omnifusion_amd.model.spherical_model import spherical_fusion
     network = spherical_fusion(args.nrows, N, (args.patchsize, args.patchsize), (args.fov, args.fov))        # test.py:104
+    if world > 1:                                              # a shard of ONE panorama must give the bits of the unsharded run
+        from omnifusion_amd.model._engine import Engine
+        Engine.latency_plan = False
     sd = torch.load(args.checkpoint, map_location="cpu") if (args.checkpoint and rank == 0) else (make_state_dict(42, N, args.iterative) if rank == 0 else None)
     sd = dist.broadcast_state_dict(sd, src=0)                                                                # one reader, RCCL broadcast
     network.load_state_dict(sd)

@@ -77,3 +77,25 @@ def test_device_feeder_delivers_every_batch_in_order():
     assert len(outs) == 7
     for (_, got), fr in zip(outs, batches):
         assert np.array_equal(got.cpu().numpy(), io_ref.preprocess_rgb(fr, 32, 64))
+
+
+def test_device_feeder_with_a_consumer_on_other_streams():
+    """`out_buffers=2` + `done_with(rgb, pending.input_read)`: pipelined forwards read the staging buffers on their own streams —
+    every batch must reach its forward unmodified (same depth as a plain call on a private copy)"""
+    from omnifusion_amd.data import DeviceFeeder, preprocess_rgb
+    from omnifusion_amd.model.spherical_model import spherical_fusion
+    from omnifusion_amd.weights import make_state_dict
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rng = np.random.default_rng(10)
+    batches = [torch.from_numpy(rng.integers(0, 256, (2, 128, 256, 3), dtype=np.uint8)).pin_memory() for _ in range(9)]
+    want = [net(preprocess_rgb(b.cuda(), (128, 256))).clone() for b in batches]
+    run = net.pipelined(3)
+    feeder = DeviceFeeder(batches, (128, 256), depth=3, out_buffers=2)
+    pend = []
+    for rgb in feeder:
+        p = run(rgb)
+        feeder.done_with(rgb, p.input_read)
+        pend.append(p)
+    got = [p.get() for p in pend]
+    assert len(got) == 9 and all(torch.equal(g, w) for g, w in zip(got, want))

@@ -1,1 +1,1 @@
-timeout 300 python tools/pair_conc.py 2>&1 | grep -v amdgpu.ids
+timeout 900 python -m pytest tests/test_io_gpu.py -x -q -m gpu 2>&1 | tail -3

@@ -684,17 +684,21 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
         return OMNI_OK;
     }
     // tile: results do not depend on it (every output element is the same k-ordered chain), so it is a pure tuning choice
-    // -1 auto: the largest 8-wave tile the layer allows (128x128, else 128x64: half / three quarters of the L2 -> LDS bytes per MFMA of a
-    // 64x64 tile) wherever the launch still has >= 128 blocks, 64x64 below that.  Measured interleaved in one process (tools/pipe_ab.py,
-    // tools/plain_ab.py): +5.1 % panoramas/s with three forwards in flight, +1.7 % for plain calls at 8 panoramas, -1 % at 4, 0 at 1.
-    // 0: 64x64 everywhere; 1: 128x64 (4 waves); 2: 128x128 (4 waves); 3 / 4: the 8-wave forms everywhere; 5 / 7: auto with 64 / 256 blocks
+    // -1 auto (= 8): the largest 8-wave tile the layer allows (256x128, 128x128, else 128x64: 3/8, 1/2, 3/4 of the L2 -> LDS bytes per MFMA
+    // of a 64x64 tile) wherever the launch still has >= 128 blocks, 64x64 below that.  Measured interleaved in one process
+    // (tools/pipe_ab.py, tools/plain_ab.py): +5.1 % panoramas/s with three forwards in flight (+1.2 % of it from 256x128), +1.7 % for plain
+    // calls at 8 panoramas, -1 % at 4, 0 at 1.
+    // 0: 64x64 everywhere; 1: 128x64 (4 waves); 2: 128x128 (4 waves); 3 / 4: the 8-wave forms everywhere; 5..7: auto without 256x128, with 64 / 128 / 256 blocks
     int tile = omni_options().conv_sh_tile;
-    if (tile < 0) tile = 6;
+    if (tile < 0) tile = 8;
     if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s);
     else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s);
     else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
     else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s);            // 8 waves
     else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
+    else if (tile == 8 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s);   // each wave a 64x64 tile: 0.67 KB of LDS reads per MFMA instead of 1
+    else if (tile == 8 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2>(a, s);
+    else if (tile == 8 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2>(a, s);
     else if (tile >= 5 && tile <= 7 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 128, 4, 2>(a, s);
     else if (tile >= 5 && tile <= 7 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 64, 4, 2>(a, s);
     // one round of at most one block per CU (the transformer GEMMs; every deep layer at batch 1): the K loop is pure latency,

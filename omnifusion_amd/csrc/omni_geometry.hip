@@ -33,6 +33,7 @@ const OptName kOpts[] = {
     {"e2p_notab", "OMNI_E2P_NOTAB", &OmniOptions::e2p_notab, 0},
     {"e2p_verbose", "OMNI_E2P_VERBOSE", &OmniOptions::e2p_verbose, 0},
     {"e2p_bwd_simple", "OMNI_E2P_BWD_SIMPLE", &OmniOptions::e2p_bwd_simple, 0},
+    {"p2e_bwd_simple", "OMNI_P2E_BWD_SIMPLE", &OmniOptions::p2e_bwd_simple, 0},
     {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
     {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},
     {"e2p_slot_kb", "OMNI_E2P_SLOT_KB", &OmniOptions::e2p_slot_kb, 6},
@@ -185,6 +186,8 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; }
     for (auto& t : g->e2p_boxes) { t.ent = nullptr; t.fb = nullptr; t.order = nullptr; t.norder = 0; t.nfb = 0; t.max_chunks = 0; t.ok = 0; t.tw = t.th = t.tx = t.ty = 0; }
     g->p2e_tx = g->p2e_ty = 0;
+    g->p2e_bwd_box = nullptr; g->p2e_rden = nullptr; g->p2e_btx = g->p2e_bty = g->p2e_bwd_ok = 0;
+    g->p2e_bwd_ids = nullptr; g->p2e_bwd_nsmall = g->p2e_bwd_nbig = 0;
 
     if (H > 0 && W > 0) {
         const float PI_F = (float)M_PI, PI_2_F = (float)(M_PI * 0.5);
@@ -199,6 +202,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
         OMNI_HIP(hipMemcpy(g->col_trig, ct.data(), sizeof(float2) * W, hipMemcpyHostToDevice));
         int rc = omni_p2e_build_candidates(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_p2e_build_tiles(g.get(), stream);
+        if (rc == OMNI_OK) rc = omni_p2e_build_bwd(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_tileflags(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_boxes(g.get(), stream);
         if (rc != OMNI_OK) { omni_geometry_destroy(g.release()); return rc; }
@@ -214,6 +218,9 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->col_trig) (void)hipFree(g->col_trig);
     if (g->cand) (void)hipFree(g->cand);
     for (auto& t : g->p2e_tiles) if (t.ent) (void)hipFree(t.ent);
+    if (g->p2e_bwd_box) (void)hipFree(g->p2e_bwd_box);
+    if (g->p2e_rden) (void)hipFree(g->p2e_rden);
+    if (g->p2e_bwd_ids) (void)hipFree(g->p2e_bwd_ids);
     for (auto& t : g->e2p_boxes) { if (t.ent) (void)hipFree(t.ent); if (t.fb) (void)hipFree(t.fb); if (t.order) (void)hipFree(t.order); }
     if (g->e2p_fb_tiles) (void)hipFree(g->e2p_fb_tiles);
     if (g->e2p_ixy) (void)hipFree(g->e2p_ixy);

@@ -31,6 +31,7 @@ struct OmniOptions {
     int e2p_notab;        // OMNI_E2P_NOTAB      1: no per-geometry sampling-coordinate table
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
     int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 1: plain scatter backward
+    int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 1: pers2equi backward by global atomics (the round-1 kernel) instead of patch-tile gathers
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
@@ -80,6 +81,10 @@ struct omni_geometry {
     // bilinear taps inside the patch (omni_pers2equi.hip); index 0: 4-byte elements, 1: 2-byte elements (16-byte chunk alignment)
     struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; } p2e_tiles[2];
     int p2e_tx, p2e_ty;            // tiles per ERP row / column
+    // pers2equi backward by gathers (omni_pers2equi.hip): per (patch, 4 x 32 patch tile) the ERP box of the pixels whose taps touch it
+    // (columns relative to the patch's centre column: the box may cross the +-pi seam), and 1 / (L1 norm of the tap weights) per ERP pixel
+    int4* p2e_bwd_box; float* p2e_rden; int p2e_btx, p2e_bty, p2e_bwd_ok;
+    int* p2e_bwd_ids; int p2e_bwd_nsmall, p2e_bwd_nbig;   // tile ids: [0, nsmall) boxes of <= 2048 pixels (one wave each), then the big ones (1024 threads each)
     // equi2pers LDS path (omni_equi2pers.hip, e2p_box_kernel): per (patch, sample tile) the bounding box of the bilinear taps on
     // the ERP; index 0: 4-byte elements (8 x 32 sample tiles), 1: 2-byte elements (4 x 64); fb = tiles whose box exceeds the slot
     struct E2PTiles { uint2* ent; int* fb; int nfb; int max_chunks; int tw, th, tx, ty; int ok;
@@ -97,6 +102,8 @@ int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, floa
 int omni_p2e_build_candidates(omni_geometry* g, hipStream_t stream);
 // implemented in omni_pers2equi.hip: fills g->p2e_tiles (needs g->cand)
 int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream);
+// implemented in omni_pers2equi.hip: fills g->p2e_bwd_box / p2e_rden (needs g->cand)
+int omni_p2e_build_bwd(omni_geometry* g, hipStream_t stream);
 // implemented in omni_equi2pers.hip: fills g->e2p_ixy, g->e2p_fb_tiles / e2p_nfb, then g->e2p_boxes
 int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream);
 int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream);

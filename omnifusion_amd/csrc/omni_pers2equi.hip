@@ -799,6 +799,169 @@ extern "C" int omni_pers2equi_conf(const void* pred_w, const void* conf, float* 
 // Vector-Jacobian product of pers2equi w.r.t. the patches: grad_erp [B,C,H,W] -> grad_pers in the layout of the forward's
 // input (overwritten).  fp32 only.  Replaces what autograd derives from the advanced-indexing gathers of
 // pers2equi_v3.py:174-196 in the reference's training scripts.
+namespace {
+// ---- backward by gathers (no global atomics, nothing to zero).  The scatter kernel above issues 4 global atomics per (ERP pixel, covering
+// patch, plane): 35 M of them at B = 8, 18 x 256^2 — 1.28 ms, bound by the L2 atomic rate.  Transposed, every PATCH pixel is the sum over the ERP
+// pixels whose bilinear taps touch it, and patch tiles are disjoint: one wave owns a 4 x 32 tile of one patch, walks the ERP box of the
+// pixels that can touch it (a constant of the geometry, built once with the SAME tap function — exact superset), evaluates their taps
+// for this patch, and accumulates the ones that fall into its tile in LDS (ds_add_f32: order within the wave's own instruction stream);
+// then it writes the tile once, coalesced.  An ERP pixel is visited by every tile its taps touch (1-4 per covering patch), so the tap
+// geometry is evaluated ~2.5x as often as in the forward; the L1 normaliser of a pixel (all covering patches) is a table.
+constexpr int P2B_TH = 4, P2B_TW = 32;
+
+__device__ __forceinline__ int p2b_centre_col(const P2EArgs& a, int n)
+{
+    return (int)((a.tab.lam0[n] + 3.14159265358979f) * (0.5f / 3.14159265358979f) * (float)(a.W - 1) + 0.5f);
+}
+__device__ __forceinline__ int p2b_wrap(int dx, int W)              // column difference into [-W/2, W - W/2)
+{
+    const int h = W >> 1;
+    dx = dx >= W - h ? dx - W : dx;
+    return dx < -h ? dx + W : dx;
+}
+
+// one wave per 64 ERP pixels of one row: the L1 normaliser of every pixel and, per (patch, tile), the box of the pixels touching it
+__global__ __launch_bounds__(256) void p2e_bwd_box_kernel(P2EArgs a, int* __restrict__ boxes, float* __restrict__ rden, int btx, int bty)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = blockIdx.x % a.ntx;
+    const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.ntx) * 4 + wave);
+    const int j = tx * 64 + lane;
+    if (i >= a.H) return;
+    const bool inside = j < a.W;
+    const float2 rt = a.row_trig[i];
+    const float2 ct = a.col_trig[inside ? j : a.W - 1];
+    const unsigned long long cm_ = a.cand[(size_t)i * a.ntx + tx];
+    const unsigned cm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ >> 32));
+    const unsigned cm_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ & 0xffffffffull));
+    const unsigned long long cmask = ((unsigned long long)cm_hi << 32) | (unsigned long long)cm_lo;
+    float l1 = 0.0f;
+    for (unsigned long long m = cmask; m;) {
+        const int n = __builtin_ctzll(m); m &= m - 1;
+        Taps t; p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+        const float wsum = (t.wa + t.wb) + (t.wc + t.wd);
+        l1 += wsum;
+        if (!(inside && wsum > 0.0f)) continue;
+        const int dx = p2b_wrap(j - p2b_centre_col(a, n), a.W);
+        const int xs[2] = {t.x0, t.x1}, ys[2] = {t.y0, t.y1};
+        const float w[4] = {t.wa, t.wb, t.wc, t.wd};               // (y0,x0) (y1,x0) (y0,x1) (y1,x1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (w[k] == 0.0f) continue;
+            const int id = (n * bty + ys[k & 1] / P2B_TH) * btx + xs[k >> 1] / P2B_TW;
+            atomicMin(boxes + 4 * id + 0, dx); atomicMax(boxes + 4 * id + 1, dx);
+            atomicMin(boxes + 4 * id + 2, i);  atomicMax(boxes + 4 * id + 3, i);
+        }
+    }
+    if (inside) rden[(size_t)i * a.W + j] = 1.0f / fmaxf(l1, 1e-12f);
+}
+
+// NT threads per tile: 64 for the ordinary tiles, 1024 for the few polar ones whose box is whole ERP rows (tens of thousands of pixels)
+template <int PL, int NT>
+__global__ __launch_bounds__(NT) void p2e_bwd_gather_kernel(P2EArgs a /* erp = g_erp (in), pers = g_pers (out) */, const int4* __restrict__ boxes,
+                                                            const float* __restrict__ rden, const int* __restrict__ ids, int btx, int bty, int planes)
+{
+    __shared__ float acc[PL][P2B_TH * P2B_TW];
+    const int lane = threadIdx.x;
+    const int id = ids[blockIdx.x], p0 = blockIdx.y * PL;
+    const int n = id / (btx * bty), tt = id - n * (btx * bty);
+    const int ty0 = (tt / btx) * P2B_TH, tx0 = (tt % btx) * P2B_TW;
+#pragma unroll
+    for (int p = 0; p < PL; ++p)
+        for (int e = lane; e < P2B_TH * P2B_TW; e += NT) acc[p][e] = 0.0f;
+    if (NT > 64) __syncthreads();
+    const int4 box = boxes[id];                                    // dx min, dx max, row min, row max
+    const float* gerp = (const float*)a.erp;
+    const size_t erp_plane = (size_t)a.H * a.W;
+    if (box.x <= box.y) {
+        const int bw = box.y - box.x + 1, npx = bw * (box.w - box.z + 1);
+        const int xc = p2b_centre_col(a, n);
+        const float rbw = 1.0f / (float)bw;
+        for (int base = 0; base < npx; base += NT) {
+            const int idx = base + lane;
+            const bool in = idx < npx;
+            int dy = (int)(((float)idx + 0.5f) * rbw);               // idx / bw (exact for the sizes here, fixed up below)
+            int dxi = idx - dy * bw;
+            if (dxi < 0) { --dy; dxi += bw; } else if (dxi >= bw) { ++dy; dxi -= bw; }
+            const int i = in ? box.z + dy : box.z;
+            int j = xc + box.x + (in ? dxi : 0);
+            j = j < 0 ? j + a.W : (j >= a.W ? j - a.W : j);
+            const float2 rt = a.row_trig[i], ct = a.col_trig[j];
+            Taps t; p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+            const size_t pix = (size_t)i * a.W + j;
+            const float r = in ? rden[pix] : 0.0f;
+            // tile-relative tap positions; a tap outside my tile belongs to a neighbouring wave
+            const int ya = t.y0 - ty0, yb = t.y1 - ty0, xa = t.x0 - tx0, xb = t.x1 - tx0;
+            const bool ya_in = (unsigned)ya < (unsigned)P2B_TH, yb_in = (unsigned)yb < (unsigned)P2B_TH;
+            const bool xa_in = (unsigned)xa < (unsigned)P2B_TW, xb_in = (unsigned)xb < (unsigned)P2B_TW;
+            const float wa = (ya_in && xa_in) ? t.wa * r : 0.0f, wb = (yb_in && xa_in) ? t.wb * r : 0.0f;
+            const float wc = (ya_in && xb_in) ? t.wc * r : 0.0f, wd = (yb_in && xb_in) ? t.wd * r : 0.0f;
+            if (wa == 0.0f && wb == 0.0f && wc == 0.0f && wd == 0.0f) continue;
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+                if (p0 + p >= planes) break;
+                const float g = gerp[(size_t)(p0 + p) * erp_plane + pix];
+                if (wa != 0.0f) atomicAdd(&acc[p][ya * P2B_TW + xa], g * wa);
+                if (wb != 0.0f) atomicAdd(&acc[p][yb * P2B_TW + xa], g * wb);
+                if (wc != 0.0f) atomicAdd(&acc[p][ya * P2B_TW + xb], g * wc);
+                if (wd != 0.0f) atomicAdd(&acc[p][yb * P2B_TW + xb], g * wd);
+            }
+        }
+    }
+    __syncthreads();                                               // the LDS adds of every wave are done
+    float* gp = (float*)const_cast<void*>(a.pers);
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+        if (p0 + p >= planes) break;
+        const size_t pb = (size_t)((p0 + p) / a.C) * a.sB + (size_t)((p0 + p) % a.C) * a.sC + (size_t)n * a.sN;
+        for (int e = lane; e < P2B_TH * P2B_TW; e += NT) {
+            const int y = ty0 + e / P2B_TW, x = tx0 + e % P2B_TW;
+            if (y < a.ph && x < a.pw) gp[pb + (size_t)y * a.sY + (size_t)x * a.sX] = acc[p][e];
+        }
+    }
+}
+}  // namespace
+
+int omni_p2e_build_bwd(omni_geometry* g, hipStream_t stream)
+{
+    P2EArgs a;
+    int rc = fill_args(a, g, nullptr, nullptr, nullptr, 1, 1, OMNI_LAYOUT_BNCHW);
+    if (rc != OMNI_OK) return rc;
+    g->p2e_btx = (g->pw + P2B_TW - 1) / P2B_TW; g->p2e_bty = (g->ph + P2B_TH - 1) / P2B_TH;
+    const size_t ntiles = (size_t)g->N * g->p2e_btx * g->p2e_bty;
+    if (ntiles == 0 || ntiles >= (1u << 30)) return OMNI_OK;       // no table: the scatter kernel serves this geometry
+    OMNI_HIP(hipMalloc((void**)&g->p2e_bwd_box, sizeof(int4) * ntiles));
+    OMNI_HIP(hipMalloc((void**)&g->p2e_rden, sizeof(float) * (size_t)g->H * g->W));
+    std::vector<int4> init(ntiles, make_int4(0x7fffffff, -0x7fffffff, 0x7fffffff, -0x7fffffff));
+    OMNI_HIP(hipMemcpy(g->p2e_bwd_box, init.data(), sizeof(int4) * ntiles, hipMemcpyHostToDevice));
+    const int rows4 = (g->H + 3) / 4;
+    hipLaunchKernelGGL(p2e_bwd_box_kernel, dim3(rows4 * g->ntx), dim3(256), 0, stream, a, (int*)g->p2e_bwd_box, g->p2e_rden, g->p2e_btx, g->p2e_bty);
+    OMNI_HIP(hipGetLastError());
+    OMNI_HIP(hipStreamSynchronize(stream));
+    std::vector<int4> hb(ntiles);
+    OMNI_HIP(hipMemcpy(hb.data(), g->p2e_bwd_box, sizeof(int4) * ntiles, hipMemcpyDeviceToHost));
+    std::vector<int> small, big;
+    for (size_t t = 0; t < ntiles; ++t) {
+        const long long npx = hb[t].x <= hb[t].y ? (long long)(hb[t].y - hb[t].x + 1) * (hb[t].w - hb[t].z + 1) : 0;
+        (npx <= 2048 ? small : big).push_back((int)t);
+    }
+    g->p2e_bwd_nsmall = (int)small.size(); g->p2e_bwd_nbig = (int)big.size();
+    if (omni_options().e2p_verbose) {
+        long long ps = 0, pb = 0, mx = 0;
+        for (size_t t = 0; t < ntiles; ++t) {
+            const long long npx = hb[t].x <= hb[t].y ? (long long)(hb[t].y - hb[t].x + 1) * (hb[t].w - hb[t].z + 1) : 0;
+            (npx <= 2048 ? ps : pb) += npx; mx = npx > mx ? npx : mx;
+        }
+        fprintf(stderr, "[omni] pers2equi backward boxes (%dx%d ERP, %dx%d patches): %zu tiles, %d big; box pixels small %lld big %lld, largest %lld\n",
+                g->H, g->W, g->ph, g->pw, ntiles, g->p2e_bwd_nbig, ps, pb, mx);
+    }
+    small.insert(small.end(), big.begin(), big.end());
+    OMNI_HIP(hipMalloc((void**)&g->p2e_bwd_ids, sizeof(int) * ntiles));
+    OMNI_HIP(hipMemcpy(g->p2e_bwd_ids, small.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice));
+    g->p2e_bwd_ok = 1;
+    return OMNI_OK;
+}
+
 extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dtype, int B, int C, int ph, int pw,
                                   int H, int W, int nrows, float fov_h, float fov_w, int layout, omni_stream_t stream)
 {
@@ -813,6 +976,19 @@ extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dty
     P2EArgs a;
     rc = fill_args(a, g, grad_pers, nullptr, const_cast<void*>(grad_erp), B, C, layout);
     if (rc != OMNI_OK) return rc;
+    if (g->p2e_bwd_ok && !omni_options().p2e_bwd_simple) {
+        constexpr int PL = 4;
+        const int groups = (B * C + PL - 1) / PL;
+        if (g->p2e_bwd_nbig)                                      // first: they are the long ones
+            hipLaunchKernelGGL((p2e_bwd_gather_kernel<PL, 1024>), dim3(g->p2e_bwd_nbig, groups), dim3(1024), 0, (hipStream_t)stream, a,
+                               (const int4*)g->p2e_bwd_box, (const float*)g->p2e_rden, (const int*)g->p2e_bwd_ids + g->p2e_bwd_nsmall,
+                               g->p2e_btx, g->p2e_bty, B * C);
+        if (g->p2e_bwd_nsmall)
+            hipLaunchKernelGGL((p2e_bwd_gather_kernel<PL, 64>), dim3(g->p2e_bwd_nsmall, groups), dim3(64), 0, (hipStream_t)stream, a,
+                               (const int4*)g->p2e_bwd_box, (const float*)g->p2e_rden, (const int*)g->p2e_bwd_ids, g->p2e_btx, g->p2e_bty, B * C);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
+    }
     OMNI_HIP(hipMemsetAsync(grad_pers, 0, (size_t)B * C * g->N * ph * pw * sizeof(float), (hipStream_t)stream));
     const int rows4 = (g->H + 3) / 4, nblocks = rows4 * g->ntx;
     hipLaunchKernelGGL(p2e_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a, nblocks);

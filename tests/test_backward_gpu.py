@@ -85,3 +85,30 @@ def test_adjoint_identity_config1_size():
     (e * z).sum().backward()
     lhs = float((e.detach().double() * z.double()).sum()); rhs = float((p.detach().double() * p.grad.double()).sum())
     assert abs(lhs - rhs) <= 2e-5 * abs(lhs)
+
+
+def test_pers2equi_backward_gather_equals_scatter():
+    """the atomic-free patch-tile gather kernel (default) against the round-1 scatter kernel (global atomics), at the benchmark size,
+    at nrows = 6 (boxes that wrap around the +-pi seam and polar tiles that see a whole ERP row) and on ragged patch tiles"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    for B, C, nrows, (ph, pw), (H, W) in ((8, 1, 4, (256, 256), (512, 1024)), (2, 2, 6, (128, 128), (512, 1024)), (1, 3, 3, (37, 50), (120, 250)),
+                                          (2, 1, 5, (64, 64), (256, 512))):
+        N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+        ge = torch.rand((B, C, H, W), device=DEV)
+        outs = []
+        try:
+            for simple in (0, 1):
+                L.set_option("p2e_bwd_simple", simple)
+                gp = torch.full((B, N, C, ph, pw), float("nan"), device=DEV)
+                rc = lib.omni_pers2equi_bwd(P_(ge), P_(gp), 0, B, C, ph, pw, H, W, nrows, ctypes.c_float(80), ctypes.c_float(80), L.LAYOUT_BNCHW, None)
+                assert rc == 0, lib.omni_last_error()
+                outs.append(gp)
+        finally:
+            L.set_option("p2e_bwd_simple", 0)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(outs[0]).all())
+        d = (outs[0] - outs[1]).abs().max().item()
+        assert d <= 1e-5 * max(1.0, outs[1].abs().max().item()), (nrows, ph, pw, d)

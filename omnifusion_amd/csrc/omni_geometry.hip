@@ -188,6 +188,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     g->p2e_tx = g->p2e_ty = 0;
     g->p2e_bwd_box = nullptr; g->p2e_rden = nullptr; g->p2e_btx = g->p2e_bty = g->p2e_bwd_ok = 0;
     g->p2e_bwd_ids = nullptr; g->p2e_bwd_nsmall = g->p2e_bwd_nbig = 0;
+    g->e2p_bwd_box = nullptr; g->e2p_bwd_ids = nullptr; g->e2p_bwd_nsmall = g->e2p_bwd_nbig = g->e2p_gtx = g->e2p_gty = g->e2p_bwd_ok = 0;
 
     if (H > 0 && W > 0) {
         const float PI_F = (float)M_PI, PI_2_F = (float)(M_PI * 0.5);
@@ -205,6 +206,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
         if (rc == OMNI_OK) rc = omni_p2e_build_bwd(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_tileflags(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_boxes(g.get(), stream);
+        if (rc == OMNI_OK) rc = omni_e2p_build_bwd(g.get(), stream);
         if (rc != OMNI_OK) { omni_geometry_destroy(g.release()); return rc; }
     }
     *out = g.release();
@@ -224,6 +226,8 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     for (auto& t : g->e2p_boxes) { if (t.ent) (void)hipFree(t.ent); if (t.fb) (void)hipFree(t.fb); if (t.order) (void)hipFree(t.order); }
     if (g->e2p_fb_tiles) (void)hipFree(g->e2p_fb_tiles);
     if (g->e2p_ixy) (void)hipFree(g->e2p_ixy);
+    if (g->e2p_bwd_box) (void)hipFree(g->e2p_bwd_box);
+    if (g->e2p_bwd_ids) (void)hipFree(g->e2p_bwd_ids);
     delete g;
 }
 

@@ -30,7 +30,7 @@ struct OmniOptions {
     int e2p_gather;       // OMNI_E2P_GATHER     1: equi2pers always takes the direct-gather kernel (no LDS staging)
     int e2p_notab;        // OMNI_E2P_NOTAB      1: no per-geometry sampling-coordinate table
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
-    int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 1: plain scatter backward
+    int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 0: fastest per layout (planar: LDS boxes + global atomics; reference layout: ERP-tile gathers, no global atomics) | 1: plain scatter | 2: LDS boxes | 3: gathers
     int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 1: pers2equi backward by global atomics (the round-1 kernel) instead of patch-tile gathers
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
@@ -93,6 +93,8 @@ struct omni_geometry {
     int e2p_nfb;
     int e2p_ts;                    // equi2pers: tile side (32 or 16 samples) chosen so that the footprints fit the LDS box
     float2* e2p_ixy;               // equi2pers: clamped sampling coordinates (ix, iy) of every patch sample [N][ph][pw]
+    // equi2pers backward by gathers (omni_equi2pers.hip): per (4 x 32 ERP tile, patch) the box of the patch samples whose taps touch the tile
+    int4* e2p_bwd_box; int* e2p_bwd_ids; int e2p_bwd_nsmall, e2p_bwd_nbig, e2p_gtx, e2p_gty, e2p_bwd_ok;
 };
 
 // implemented in omni_geometry.hip
@@ -107,6 +109,7 @@ int omni_p2e_build_bwd(omni_geometry* g, hipStream_t stream);
 // implemented in omni_equi2pers.hip: fills g->e2p_ixy, g->e2p_fb_tiles / e2p_nfb, then g->e2p_boxes
 int omni_e2p_build_tileflags(omni_geometry* g, hipStream_t stream);
 int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream);
+int omni_e2p_build_bwd(omni_geometry* g, hipStream_t stream);        // fills g->e2p_bwd_* (needs g->e2p_ixy)
 
 // ---------------------------------------------------------------- storage types
 template <typename T> struct Store;

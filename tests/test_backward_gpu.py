@@ -112,3 +112,33 @@ def test_pers2equi_backward_gather_equals_scatter():
         assert bool(torch.isfinite(outs[0]).all())
         d = (outs[0] - outs[1]).abs().max().item()
         assert d <= 1e-5 * max(1.0, outs[1].abs().max().item()), (nrows, ph, pw, d)
+
+
+def test_equi2pers_backward_gather_equals_scatter():
+    """the atomic-free ERP-tile gather kernel (default) against the plain scatter kernel and the round-1 LDS-box kernel (global atomics),
+    both layouts, the benchmark size, nrows = 6, ragged ERP tiles and odd x odd patches (NaN centre sample, quirk q4)"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    for B, C, nrows, (ph, pw), (H, W) in ((8, 3, 4, (256, 256), (512, 1024)), (1, 1, 6, (64, 64), (512, 1024)), (2, 2, 3, (9, 13), (50, 99)),
+                                          (2, 1, 5, (32, 32), (130, 260))):
+        N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+        for layout in (L.LAYOUT_BNCHW, L.LAYOUT_BCHWN):
+            gp = torch.rand((B, N, C, ph, pw) if layout == L.LAYOUT_BNCHW else (B, C, ph, pw, N), device=DEV)
+            outs = []
+            try:
+                for mode in (3, 1, 2):
+                    L.set_option("e2p_bwd_simple", mode)
+                    ge = torch.full((B, C, H, W), float("nan"), device=DEV)
+                    rc = lib.omni_equi2pers_bwd(P_(gp), P_(ge), 0, B, C, H, W, ph, pw, nrows, ctypes.c_float(80), ctypes.c_float(80), layout, None)
+                    assert rc == 0, lib.omni_last_error()
+                    outs.append(ge)
+            finally:
+                L.set_option("e2p_bwd_simple", 0)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(outs[0]).all())
+            scale = max(1.0, outs[1].abs().max().item())
+            for k in (1, 2):
+                d = (outs[0] - outs[k]).abs().max().item()
+                assert d <= 2e-5 * scale, (nrows, ph, pw, layout, k, d)

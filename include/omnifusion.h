@@ -170,6 +170,15 @@ int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16
                             const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                             int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                             omni_stream_t stream);
+/* The nn.Linear layers of ONE panorama's transformer (model/blocks.py:19-21,43-46 at 18 tokens): out[rows, N] =
+ * act(x . W^T + bias + res) for rows <= 32.  x SH [rows, K], res fp32 [rows, N] or null, fmt bit 0: dst is SH
+ * (else fp32).  K in {512, 2048}, N % 32 == 0.  Operands go straight into registers, K is split over the waves of a block and
+ * summed in a fixed order: equal to omni_conv2d_sh_f16x3_ws (H = W = KH = KW = 1) up to fp32 rounding, not bit for bit.
+ * wt16r is the weight matrix in FRAGMENT ORDER (a wave's load = one contiguous KiB): omni_gemm_rows_pack makes it, once at load
+ * time, from wt16 [N][K/32][hi32|lo32] (same size). */
+int omni_gemm_rows_sh_f16x3(const void* x, const void* wt16r, const float* bias, const float* res, void* dst, int fmt,
+                            int rows, int K, int N, int act, omni_stream_t stream);
+int omni_gemm_rows_pack(const void* wt16, void* wt16r, int N, int K, omni_stream_t stream);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a

@@ -530,7 +530,9 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
     ShConvArgs e;
     e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst;
 
-    for (int ox0 = 0; ox0 < Po; ox0 += SM_TW) {
+    // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
+    const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
+    for (int ox0 = ox_first; ox0 < ox_last; ox0 += SM_TW) {
         const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
         __syncthreads();                                          // the previous tile's fragment reads are done
         for (int i = t; i < 3 * SM_IH * SM_IP; i += 256) {        // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
             if (q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) v = src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix];
             img[i] = v;
         }
-        if (ox0 == 0) wait_vm<0>();                               // the filter bank has landed
+        if (ox0 == ox_first) wait_vm<0>();                        // the filter bank has landed
         __syncthreads();
         f16v acc[2], acc1[2];
 #pragma unroll
@@ -623,6 +625,92 @@ __global__ __launch_bounds__(256) void sh_to_f32_kernel(const void* __restrict__
     if (i >= n4) return;
     const unsigned char* sp = (const unsigned char*)src + sh_off(i * 4);
     *reinterpret_cast<f4v*>(dst + i * 4) = sh_join4(*reinterpret_cast<const h4v*>(sp), *reinterpret_cast<const h4v*>(sp + 64));
+}
+
+// ------------------------------------------------------------------ GEMM over a handful of rows (a lone panorama's tokens)
+// out[rows <= 32, N] = act(x[rows, K] . W[N, K]^T + bias + res): the 24 transformer GEMMs of ONE panorama have 18 rows — one column
+// tile of the matrix instruction — and are nothing but a stream of weights (1-4 MB each) behind a launch.  Through the tile kernel
+// above they cost 8-19 us each (16-64 barrier-synchronised K-steps through LDS, fc2 a split-K launch plus its reduction); here a block
+// owns 32 output channels, its 8 waves split K between them and fetch both operands STRAIGHT INTO REGISTERS in fragment order (no LDS,
+// no barrier in the K loop, up to four K-steps = 32 sixteen-byte loads per lane in flight), and the 8 partial tiles meet once in LDS
+// in a fixed order.  Within a 32-channel group lane half h takes halfs 16h .. 16h+15 (32 contiguous bytes) for BOTH operands: which k
+// meets which inside one matrix instruction is free as long as the two sides agree.
+struct RowsGemmArgs {
+    const void* x; const void* wt; const float* bias; const float* res; void* dst;
+    int rows, K, N, act, dst_sh;
+};
+
+// dst (fragment order, see gemm_rows_sh_kernel) <- src [N][K/32][hi32|lo32]; one 16-byte piece per thread
+__global__ __launch_bounds__(256) void gemm_rows_pack_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int ksteps, size_t pieces)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pieces) return;
+    const int lane = i & 63, f = (i >> 6) & 3;
+    const size_t bk = i >> 8;
+    const int ks = bk % ksteps; const size_t b = bk / ksteps;
+    const int r = lane & 31, h = lane >> 5, part = f >> 1, kc = f & 1;
+    *reinterpret_cast<f4v*>(dst + i * 16) = *reinterpret_cast<const f4v*>(src + ((b * 32 + r) * ksteps + ks) * 128 + part * 64 + (h * 16 + kc * 8) * 2);
+}
+
+template <int KPW>                                               // K-steps per wave (K = 256 * KPW)
+__global__ __launch_bounds__(512) void gemm_rows_sh_kernel(RowsGemmArgs a)
+{
+    constexpr int NWV = 8, DEPTH = KPW < 4 ? KPW : 4, PITCH = 36;
+    __shared__ float red[NWV][32][PITCH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.x * 32, ksteps = a.K >> 5, ks0 = wave * KPW;
+    // weights in FRAGMENT ORDER (omni_gemm_rows_pack): [column tile][K-step][hi kc0, hi kc1, lo kc0, lo kc1][lane] x 16 B — a wave's load is
+    // one contiguous KiB (8 cache lines) instead of 32 B out of each of 32 lines 8 KiB apart, which made the address unit the bound
+    const unsigned char* wp = (const unsigned char*)a.wt + ((size_t)blockIdx.x * ksteps + ks0) * 4096 + lane * 16;
+    const unsigned char* xp = (const unsigned char*)a.x + ((size_t)r * ksteps + ks0) * 128 + h * 32;
+    const bool live = r < a.rows;                                // token columns past the end stay zero and are never stored
+    h8v wh[DEPTH][2], wl[DEPTH][2], xh[DEPTH][2], xl[DEPTH][2];
+    auto fetch = [&](int slot, int i) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            wh[slot][kc] = *reinterpret_cast<const h8v*>(wp + i * 4096 + kc * 1024);
+            wl[slot][kc] = *reinterpret_cast<const h8v*>(wp + i * 4096 + 2048 + kc * 1024);
+            xh[slot][kc] = live ? *reinterpret_cast<const h8v*>(xp + i * 128 + kc * 16) : (h8v)(_Float16)0.0f;
+            xl[slot][kc] = live ? *reinterpret_cast<const h8v*>(xp + i * 128 + 64 + kc * 16) : (h8v)(_Float16)0.0f;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) fetch(i, i);
+    f16v acc = (f16v)(0.0f), acc1 = (f16v)(0.0f);
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i % DEPTH][kc], xh[i % DEPTH][kc], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i % DEPTH][kc], xh[i % DEPTH][kc], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i % DEPTH][kc], xl[i % DEPTH][kc], acc1, 0, 0, 0);
+        }
+        if (i + DEPTH < KPW) fetch(i % DEPTH, i + DEPTH);
+    }
+    // D = W x tokens: column (lane & 31) = token, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * q + e], 4.8828125e-4f, acc[4 * q + e]);
+        *reinterpret_cast<f4v*>(&red[wave][r][8 * q + 4 * h]) = v;
+    }
+    __syncthreads();
+    const int tok = t >> 3, c4 = (t & 7) * 4;
+    if (t >= 256 || tok >= a.rows) return;
+    f4v v = *reinterpret_cast<const f4v*>(&red[0][tok][c4]);
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) v += *reinterpret_cast<const f4v*>(&red[w][tok][c4]);
+    const size_t o = (size_t)tok * a.N + col0 + c4;
+    if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + col0 + c4);
+    if (a.res) v += *reinterpret_cast<const f4v*>(a.res + o);
+    if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (a.dst_sh) act_store4<true>(a.dst, o, v);
+    else          act_store4<false>(a.dst, o, v);
 }
 
 template <int BM, int BN, int WM, int WN, int NST = 3>
@@ -715,6 +803,34 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     return OMNI_OK;
 }
 
+// Weights of omni_gemm_rows_sh_f16x3: wt16 [N][K/32][hi32|lo32] (as for omni_conv2d_sh_f16x3_ws) -> fragment order, same size.
+extern "C" int omni_gemm_rows_pack(const void* wt16, void* wt16r, int N, int K, omni_stream_t stream)
+{
+    if (!wt16 || !wt16r || N <= 0 || N % 32 || K <= 0 || K % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_pack: null pointer or N, K not multiples of 32");
+    const size_t pieces = (size_t)N * (K / 32) * 8;
+    hipLaunchKernelGGL(gemm_rows_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)wt16, (unsigned char*)wt16r, K / 32, pieces);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// out[rows, N] = act(x . W^T + bias + res) for rows <= 32 (see gemm_rows_sh_kernel): x SH [rows, K], wt16r from omni_gemm_rows_pack,
+// res fp32 [rows, N] or null, fmt bit 0: dst is SH (else fp32).  K in {512, 2048}, N % 32 == 0.  The K summation order differs from the
+// tile kernel's: equal to it up to fp32 rounding, not bit for bit.
+extern "C" int omni_gemm_rows_sh_f16x3(const void* x, const void* wt16, const float* bias, const float* res, void* dst, int fmt,
+                                       int rows, int K, int N, int act, omni_stream_t stream)
+{
+    if (!x || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_sh: null pointer");
+    if (rows <= 0 || rows > 32 || N <= 0 || N % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_sh: 1..32 rows, N a multiple of 32");
+    if (K != 512 && K != 2048) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_gemm_rows_sh: K must be 512 or 2048");
+    RowsGemmArgs a;
+    a.x = x; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.rows = rows; a.K = K; a.N = N; a.act = act; a.dst_sh = fmt & 1;
+    if (K == 512) hipLaunchKernelGGL(gemm_rows_sh_kernel<2>, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a);
+    else          hipLaunchKernelGGL(gemm_rows_sh_kernel<8>, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
 // conv1 7x7 s2 p3 (3 -> 64) + bn1 + ReLU on the fp16 matrix cores.  src planar [M,3,P,P]; wt16: the folded filter bank as
 // [64][192] with k = (c*7 + ky)*8 + kx (kx = 7 and k >= 168: zeros), split like every other f16x3 weight matrix
 // ([64][6][hi32|lo32]); dst SH [M,P/2,P/2,64].
@@ -723,7 +839,9 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
     if (!src || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_stem: null pointer");
     if (P % 32 || M <= 0) OMNI_FAIL(OMNI_ERR_INVALID, "omni_stem_sh_f16x3: patch size must be a multiple of 32");
     const int Po = P / 2;
-    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(M * (Po / SM_TH)), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po);
+    const int strips = M * (Po / SM_TH);
+    const int split = (strips < 256 && Po % (4 * SM_TW) == 0) ? 4 : (strips < 512 && Po % (2 * SM_TW) == 0) ? 2 : 1;    // same bits either way
+    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

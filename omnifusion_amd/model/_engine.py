@@ -182,6 +182,7 @@ class Engine:
     NOMINAL_BATCH = 8
     SINGLE_BATCH = 4           # the batch a lone panorama plans its split-K factors for (latency_plan)
     latency_plan = True
+    rows_gemm = True           # ... and its transformer GEMMs (18 rows) take the register-streaming kernel
 
     def _splitk(self, rows, Cout, ksteps, device):
         """Split factor planned for a NOMINAL batch (not the actual one), so that the K summation order — and with it
@@ -219,10 +220,28 @@ class Engine:
         _lib.check(rc, "gemm " + wkey)
         return out
 
+    def _rows_weights(self, w16key, Nout, K):
+        """the transformer matrix `w16key` in the fragment order of omni_gemm_rows_sh_f16x3 (made on first use: only single-panorama
+        forwards need the second copy, 75 MB for the six layers)"""
+        key = w16key + ".rows"
+        w = self.w.get(key)
+        if w is None:
+            src = self.w[w16key]
+            w = torch.empty_like(src)
+            _lib.check(_lib.load().omni_gemm_rows_pack(_p(src), _p(w), Nout, K, self._s), "gemm_rows_pack")
+            if not torch.cuda.is_current_stream_capturing():     # engines on other streams share the dict: hand over a finished tensor
+                torch.cuda.current_stream(src.device).synchronize()
+            self.w[key] = w
+        return w
+
     def _gemm_sh(self, x, w16key, bkey, rows, K, Nout, act=ACT_NONE, res=None, out_sh=False):
         """f16x3 GEMM on an SH activation matrix x [rows, K]; res (fp32) and bias optional; result fp32 or SH"""
         lib = _lib.load()
         out = torch.empty((rows, Nout), dtype=torch.float32, device=x.device)
+        if self._bs == 1 and self.latency_plan and self.rows_gemm and rows <= 32 and K in (512, 2048):      # a lone panorama: the register-streaming form
+            _lib.check(lib.omni_gemm_rows_sh_f16x3(_p(x), _p(self._rows_weights(w16key, Nout, K)), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
+                                                   1 if out_sh else 0, rows, K, Nout, act, self._s), "gemm " + w16key)
+            return out
         S, ws, nb = (1, None, 0) if K <= 512 else self._splitk(rows, Nout, K // 32, x.device)
         rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), None, _p(self.w[w16key]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
                                          (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws),

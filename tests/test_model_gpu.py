@@ -27,6 +27,47 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+@pytest.mark.parametrize("cfg", [(18, 512, 1536, 0, False, False), (18, 512, 512, 0, True, False), (18, 512, 2048, 2, False, True),
+                                 (18, 2048, 512, 0, True, False), (1, 512, 64, 1, False, False), (32, 2048, 96, 0, True, True)])
+def test_gemm_rows_vs_torch(cfg):
+    """omni_gemm_rows_sh_f16x3 (the transformer GEMMs of a lone panorama) against float64 torch and against the tile kernel."""
+    L, lib = _lib()
+    rows, K, N, act, use_res, out_sh = cfg
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, K, generator=g); w = torch.randn(N, K, generator=g) / np.sqrt(K); b = torch.randn(N, generator=g)
+    res = torch.randn(rows, N, generator=g) if use_res else None
+    ref = x.double() @ w.double().t() + b.double()
+    if use_res:
+        ref = ref + res.double()
+    ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    X, B, R, W16 = x.to(DEV), b.to(DEV), res.to(DEV) if use_res else None, split_weights_f16x3(w).to(DEV)
+    XS = torch.empty_like(X)
+    assert lib.omni_sh_from_f32(_p(X), _p(XS), ctypes.c_size_t(X.numel()), _stream()) == 0
+    def f32(t):
+        if not out_sh:
+            return t
+        o = torch.empty_like(t)
+        assert lib.omni_sh_to_f32(_p(t), _p(o), ctypes.c_size_t(t.numel()), _stream()) == 0
+        return o
+    out = torch.full((rows, N), float("nan"), device=DEV)
+    guard = torch.zeros(64, device=DEV)                              # rows past `rows` are computed but must never be stored
+    W16R = torch.empty_like(W16)
+    assert lib.omni_gemm_rows_pack(_p(W16), _p(W16R), N, K, _stream()) == 0, lib.omni_last_error()
+    assert torch.equal(W16R.flatten().sort().values, W16.flatten().sort().values)            # a permutation
+    rc = lib.omni_gemm_rows_sh_f16x3(_p(XS), _p(W16R), _p(B), _p(R), _p(out), 1 if out_sh else 0, rows, K, N, act, _stream())
+    assert rc == 0, lib.omni_last_error()
+    assert (f32(out).cpu().double() - ref).abs().max().item() < 3e-5
+    assert guard.abs().max().item() == 0
+    tile = torch.empty((rows, N), device=DEV)
+    rc = lib.omni_conv2d_sh_f16x3_ws(_p(XS), None, _p(W16), _p(B), _p(R), _p(tile), (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, N, 1, 1, 1, 0, act,
+                                     1, None, ctypes.c_size_t(0), _stream())
+    assert rc == 0, lib.omni_last_error()
+    assert (f32(out) - f32(tile)).abs().max().item() < 1e-5
+    assert lib.omni_gemm_rows_sh_f16x3(_p(XS), _p(W16R), _p(B), _p(R), _p(out), 0, 33, K, N, act, _stream()) == 1        # OMNI_ERR_INVALID
+    assert lib.omni_gemm_rows_sh_f16x3(_p(XS), _p(W16R), _p(B), _p(R), _p(out), 0, rows, 1024, N, act, _stream()) == 3    # OMNI_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("cfg", [
     # M, H, W, C1, C2, Cout, k, stride, pad, act, res
     (3, 16, 16, 64, 0, 64, 3, 1, 1, 1, True),

@@ -161,13 +161,14 @@ class Engine:
         return bool(flag.value)
 
     # ------------------------------------------------------------------ operator shims
-    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True, out_f32=False):
+    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True, out_f32=False, out=None):
         """One convolution (+ folded BN, bias, residual, activation).  In the f16x3 mode the activations x, x2, res and
         the result are split-half (SH) tensors (csrc/omni_sh.h) unless out_f32 asks for a plain fp32 NHWC result."""
         lib = _lib.load()
         Ho = (H + 2 * pad - k) // stride + 1
         Wo = (Wd + 2 * pad - k) // stride + 1
-        out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
         b = _p(self.w[key + ".b"]) if bias else None
         if self.sh:
@@ -279,13 +280,16 @@ class Engine:
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         conv1 = new(M, P2, P2, 64)
         sh = self.sh                                                # activations between the convolutions: SH or fp32 NHWC
-        if sh and P % 32 == 0:
-            _lib.check(lib.omni_stem_sh_f16x3(_p(patches), _p(self.w["stem.w16"]), _p(self.w["stem.b"]), _p(conv1), M, P, self._s), "stem")
-        else:
-            _lib.check((lib.omni_stem_sh if sh else lib.omni_stem_f32)(_p(patches), _p(self.w["stem.w"]), _p(self.w["stem.b"]),
-                                                                        _p(conv1), M, P, self._s), "stem")
         x = new(M, P4, P4, 64)
-        _lib.check((lib.omni_maxpool3x3s2_sh if sh else lib.omni_maxpool3x3s2_f32)(_p(conv1), _p(x), M, P2, P2, 64, self._s), "maxpool")
+        pat = patches.view(M, 3, P, P)
+        for m0, m1 in self._chunks(bs, N, self.front_chunk):        # stem -> maxpool per chunk: conv1 is re-read while still cached
+            Mc = m1 - m0
+            if sh and P % 32 == 0:
+                _lib.check(lib.omni_stem_sh_f16x3(_p(pat[m0:m1]), _p(self.w["stem.w16"]), _p(self.w["stem.b"]), _p(conv1[m0:m1]), Mc, P, self._s), "stem")
+            else:
+                _lib.check((lib.omni_stem_sh if sh else lib.omni_stem_f32)(_p(pat[m0:m1]), _p(self.w["stem.w"]), _p(self.w["stem.b"]),
+                                                                            _p(conv1[m0:m1]), Mc, P, self._s), "stem")
+            _lib.check((lib.omni_maxpool3x3s2_sh if sh else lib.omni_maxpool3x3s2_f32)(_p(conv1[m0:m1]), _p(x[m0:m1]), Mc, P2, P2, 64, self._s), "maxpool")
         feats = {}
         cin, size = 64, P4
         for lname, nblk, stride in _LAYERS:
@@ -345,16 +349,33 @@ class Engine:
         up = self._up(x, M, P8, P8, 64, P4, P4)
         x = self._conv(up, "de_conv2_0", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU)
         x = self._conv(x, "de_conv2_1", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU, x2=layer1, C2=64)
-        up = self._up(x, M, P4, P4, 64, P2, P2)
-        x = self._conv(up, "de_conv3_0", M, P2, P2, 64, 64, 3, 1, 1, ACT_RELU)
-        x = self._conv(x, "de_conv3_1", M, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1, C2=64)
-        up = self._up(x, M, P2, P2, 32, P, P)
-        x = self._conv(up, "de_conv4_0", M, P, P, 32, 32, 3, 1, 1, ACT_RELU, out_f32=True)
+        # The two widest stages move 150-300 MB per tensor at 8 panoramas, more than the 256 MB memory-side cache holds.  Run them a few
+        # panoramas at a time (same kernels, same bits: no operator here mixes patches) and part of a chunk's intermediates is still
+        # cached when their consumer starts — a small effect (+1.3 % with three forwards in flight), these layers are not purely HBM-bound.
         a, c = out if out is not None else (new(bs, N, 1, P, P), new(bs, N, 1, P, P) if confidence else None)
-        _lib.check(lib.omni_heads_f32(_p(x), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]),
-                                      ctypes.c_float(self.head_bias[1]), _p(a), _p(c), M, P, 1 if confidence else 0, self._s), "heads")
-        self.last = {"de_conv4_0": x, "layer4": layer4}
+        av, cv = a.view(M, P, P), c.view(M, P, P) if c is not None else None
+        x_in, de4 = x, new(M, P, P, 32)
+        for m0, m1 in self._chunks(bs, N, self.tail_chunk):
+            Mc = m1 - m0
+            up = self._up(x_in[m0:m1], Mc, P4, P4, 64, P2, P2)
+            x = self._conv(up, "de_conv3_0", Mc, P2, P2, 64, 64, 3, 1, 1, ACT_RELU)
+            x = self._conv(x, "de_conv3_1", Mc, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1[m0:m1], C2=64)
+            up = self._up(x, Mc, P2, P2, 32, P, P)
+            self._conv(up, "de_conv4_0", Mc, P, P, 32, 32, 3, 1, 1, ACT_RELU, out_f32=True, out=de4[m0:m1])
+            _lib.check(lib.omni_heads_f32(_p(de4[m0:m1]), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]), ctypes.c_float(self.head_bias[1]),
+                                          _p(av[m0:m1]), _p(cv[m0:m1]) if cv is not None else None, Mc, P, 1 if confidence else 0, self._s), "heads")
+        self.last = {"de_conv4_0": de4, "layer4": layer4}
         return a, c
+
+    # measured interleaved (tools/chunk_ab.py, 8 panoramas, 3 forwards in flight): tail 4 +1.2..1.4 %, tail 2 the same, tail 1 -2 %; the
+    # front (stem -> max-pool) gains nothing; plain calls (two 4-panorama lanes) are unchanged by 4 and lose 1.6 % with 2
+    tail_chunk = 4             # panoramas per pass through the decoder's two widest stages (0: the whole batch at once)
+    front_chunk = 0            # ... and through stem -> max-pool
+
+    @staticmethod
+    def _chunks(bs, N, per):
+        per = bs if per <= 0 else min(per, bs)
+        return [(b0 * N, min(bs, b0 + per) * N) for b0 in range(0, bs, per)]
 
     def blend(self, a, c, erp_hw):
         P = self.patch_size

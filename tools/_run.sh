@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 600 python tools/lat1.py
+timeout 900 python tools/chunk_ab.py

@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 900 python tools/chunk_ab.py
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3

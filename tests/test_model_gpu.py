@@ -552,6 +552,14 @@ def test_kernels_are_correct_beside_another_streams_convolutions():
     victims = {"pers2equi": lambda: pers2equi(a0, 80, 4, P, (512, 1024), None, layout=lay),
                "pers2equi_conf": lambda: pers2equi_conf(a0, c0, 80, 4, P, (512, 1024), layout=lay),
                "equi2pers": lambda: equi2pers_patches(rgb, 80, 4, P, layout=lay)}
+    gx = torch.randn(18, 2048, device=DEV); gxs = torch.empty_like(gx); lib.omni_sh_from_f32(P_(gx), P_(gxs), ctypes.c_size_t(gx.numel()), L.stream_of(gx))
+    gw = split_weights_f16x3(torch.randn(512, 2048) / 45.0).to(DEV); gwr = torch.empty_like(gw)
+    assert lib.omni_gemm_rows_pack(P_(gw), P_(gwr), 512, 2048, L.stream_of(gx)) == 0
+    def rows_gemm():
+        o = torch.empty(18, 512, device=DEV)
+        assert lib.omni_gemm_rows_sh_f16x3(P_(gxs), P_(gwr), None, None, P_(o), 0, 18, 2048, 512, 2, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        return o
+    victims["gemm_rows"] = rows_gemm
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     try:
         for gather in (0, 1):

@@ -104,6 +104,12 @@ int omni_pers2equi(const void* pers, void* erp, int dtype, int B, int C, int ph,
                    int H, int W, int nrows, float fov_h, float fov_w, int layout,
                    omni_stream_t stream);
 
+/* [B,C,ph,pw,N] (OMNI_LAYOUT_BCHWN, the reference's N-innermost patch tensor, equi2pers_v3.py:112-113) -> [B,N,C,ph,pw]
+ * (OMNI_LAYOUT_BNCHW), one coalesced pass.  The blend on planar patches is 5x faster than on the N-innermost tensor (every cache
+ * line of which is shared by all N patches): conversion + omni_pers2equi(..., OMNI_LAYOUT_BNCHW) is what the drop-in pers2equi()
+ * runs for reference-layout inputs (same result bits as omni_pers2equi(..., OMNI_LAYOUT_BCHWN)). */
+int omni_patches_to_planar(const void* src, void* dst, int dtype, int B, int C, int ph, int pw, int N, omni_stream_t stream);
+
 /*
  * Fused confidence blend — replaces model/spherical_model.py:307-311 (two pers2equi calls +
  * zero-safe division):  out = P(pred_w) / (P(conf) + 1e-8*[P(conf) <= 1e-8]),

@@ -27,7 +27,7 @@ class OmniLibraryMissing(ImportError):
 EXPORTS = [
     "omni_version", "omni_last_error", "omni_set_option", "omni_get_option", "omni_num_patches", "omni_patch_centers",
     "omni_geometry_create", "omni_geometry_destroy", "omni_geometry_cache_clear", "omni_geometry_cache_size",
-    "omni_equi2pers", "omni_equi2pers_aux", "omni_pers2equi", "omni_pers2equi_conf",
+    "omni_equi2pers", "omni_equi2pers_aux", "omni_pers2equi", "omni_pers2equi_conf", "omni_patches_to_planar",
     "omni_equi2pers_g", "omni_pers2equi_g", "omni_equi2pers_bwd", "omni_pers2equi_bwd",
     "omni_conv2d_nhwc_f32", "omni_stem_f32", "omni_maxpool3x3s2_f32", "omni_upsample_bilinear_f32",
     "omni_add_hw_f32", "omni_add_period_f32", "omni_token_pack_f32", "omni_layernorm512_f32",

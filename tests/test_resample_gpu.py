@@ -295,6 +295,32 @@ def test_lds_and_gather_paths_give_the_same_bits(cfg):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cfg", [(8, 1, 512, 1024, 4, 256, "float32"), (2, 3, 256, 512, 6, 64, "float32"), (1, 2, 128, 256, 3, 20, "float16"),
+                                 (3, 1, 64, 128, 5, 17, "float32")])
+def test_reference_layout_blend_via_planar_gives_the_same_bits(cfg):
+    """The drop-in pers2equi() converts an N-innermost patch tensor to planar (omni_patches_to_planar: a pure permutation) and
+    blends that; the direct N-innermost kernel stays available (VIA_PLANAR = False): same bits, and the conversion equals permute()."""
+    import ctypes
+    import omnifusion_amd.equi_pers.pers2equi_v3 as mod
+    _, _, pers2equi, _, L = _ops()
+    B, C, H, W, nrows, P, dtype = cfg
+    N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+    y = t(rng_uniform(71, (B, C, P, P, N))).to(getattr(torch, dtype))
+    planar = torch.empty((B, N, C, P, P), dtype=y.dtype, device=DEV)
+    assert L.load().omni_patches_to_planar(L.ptr(y), L.ptr(planar), L.dtype_code(y), B, C, P, P, N, L.stream_of(y)) == 0
+    assert torch.equal(planar, y.permute(0, 4, 1, 2, 3).contiguous())
+    floor = mod.VIA_PLANAR_MIN
+    try:
+        mod.VIA_PLANAR_MIN = 0
+        fast = pers2equi(y, 80, nrows, P, (H, W), "layer")
+        mod.VIA_PLANAR = False
+        direct = pers2equi(y, 80, nrows, P, (H, W), "layer")
+    finally:
+        mod.VIA_PLANAR, mod.VIA_PLANAR_MIN = True, floor
+    assert torch.equal(fast, direct)
+    assert torch.equal(fast, pers2equi(planar, 80, nrows, P, (H, W), None, layout=L.LAYOUT_BNCHW))
+
+
 # ------------------------------------------------------------------ edge cases and errors
 def test_edge_cases_and_errors():
     equi2pers, equi2pers_patches, pers2equi, pers2equi_conf, L = _ops()

@@ -185,6 +185,11 @@ int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16
 int omni_gemm_rows_sh_f16x3(const void* x, const void* wt16r, const float* bias, const float* res, void* dst, int fmt,
                             int rows, int K, int N, int act, omni_stream_t stream);
 int omni_gemm_rows_pack(const void* wt16, void* wt16r, int N, int K, omni_stream_t stream);
+/* F.interpolate(scale_factor 2, bilinear, align_corners=False) + ConvBnReLU (3x3, pad 1) of the decoder, model/spherical_model.py:
+ * 279-301, in ONE kernel: the up-sampled tensor never exists.  src SH [M,Hl,Wl,C], dst [M,2Hl,2Wl,Cout] SH (fmt bit 0) or fp32;
+ * 2Wl % 32 == 0 and 2Hl % 4 == 0 (else OMNI_ERR_UNSUPPORTED: omni_upsample_bilinear_sh + omni_conv2d_sh_f16x3_ws give the same bits). */
+int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, const float* bias, void* dst, int fmt,
+                              int M, int Hl, int Wl, int C, int Cout, int act, omni_stream_t stream);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a

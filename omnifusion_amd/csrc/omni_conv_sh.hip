@@ -351,9 +351,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
 constexpr int HT_W = 32, HPW = HT_W + 2;
 
 // TH = image rows per block = waves per block (4: 6x34 halo, 26 KiB; 8: 10x34 halo, 43 KiB, half the weight traffic per pixel)
-template <int BN, int TH>
+//
+// UP2: the convolution of the 2x bilinear up-sampling of src1 ([M, H/2, W/2, C1]; F.interpolate(align_corners=False) followed by
+// ConvBnReLU, model/spherical_model.py:279-301) without the up-sampled tensor ever existing: the halo patch is COMPUTED into LDS
+// instead of copied.  The 6 x 34 halo pixels are 3 x 17 cells of 2 x 2 pixels that share their four source pixels; thread
+// (cell, 8 channels) loads those once (8 x 16 B), joins hi/lo, evaluates up-sample_sh8_kernel's expression for its 4 pixels and
+// writes the 8 split pieces where the DMA would have put them (out-of-image halo pixels: zeros, the convolution's padding).
+// Same arithmetic, same bits as the two kernels it replaces; one pass over HBM less in each direction for the widest tensors.
+template <int BN, int TH, bool UP2 = false>
 __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 {
+    static_assert(!UP2 || TH == 4, "the cell decomposition of the up-sampling halo is written for 4-row tiles");
     constexpr int TN = BN / 32, NW = TH, RPP = 8 * NW;
     constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
     constexpr int APASS = (HA_INSTR + NW - 1) / NW, BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128;
@@ -403,6 +411,59 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
             }
         }
     };
+    // ---- UP2: this thread's cell of the halo and the byte offsets of its four source pixels
+    const int Hl = a.H >> 1, Wl = a.W >> 1;
+    const int u_c8 = t & 3, u_cell = t >> 2, u_ci = u_cell / 17, u_cj = u_cell - u_ci * 17;
+    const int u_k = (y0 >> 1) - 1 + u_ci, u_j = (x0 >> 1) - 1 + u_cj;
+    size_t u_src[4];
+    float u_ly[2], u_lx[2];
+    bool u_in[2][2];
+    if constexpr (UP2) {
+        const int ra = min(max(u_k, 0), Hl - 1), rb = min(max(u_k + 1, 0), Hl - 1), ca = min(max(u_j, 0), Wl - 1), cb = min(max(u_j + 1, 0), Wl - 1);
+        const size_t pp = (size_t)a.C1 * 4, img = (size_t)m * Hl * Wl;
+        u_src[0] = (img + (size_t)ra * Wl + ca) * pp + u_c8 * 16; u_src[1] = (img + (size_t)ra * Wl + cb) * pp + u_c8 * 16;
+        u_src[2] = (img + (size_t)rb * Wl + ca) * pp + u_c8 * 16; u_src[3] = (img + (size_t)rb * Wl + cb) * pp + u_c8 * 16;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {                             // the weights of up-sample_sh8_kernel for rows / columns 2k+1+d
+            const int oy = 2 * u_k + 1 + d, ox = 2 * u_j + 1 + d;
+            const float fy = fmaxf(0.5f * ((float)oy + 0.5f) - 0.5f, 0.0f), fx = fmaxf(0.5f * ((float)ox + 0.5f) - 0.5f, 0.0f);
+            u_ly[d] = fy - (float)(int)fy; u_lx[d] = fx - (float)(int)fx;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                u_in[dy][dx] = (unsigned)(2 * u_k + 1 + dy) < (unsigned)a.H && (unsigned)(2 * u_j + 1 + dx) < (unsigned)a.W;
+    }
+    auto fill_a = [&](int g) {
+        if (t >= 51 * 4) return;
+        const unsigned char* sp = (const unsigned char*)a.src1 + (size_t)g * 128;
+        h8v ch[4], cl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ch[q] = *reinterpret_cast<const h8v*>(sp + u_src[q]); cl[q] = *reinterpret_cast<const h8v*>(sp + u_src[q] + 64); }
+        float v[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[q][e] = fmaf((float)cl[q][e], 4.8828125e-4f, (float)ch[q][e]);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float ly = u_ly[dy], lx = u_lx[dx], hy = 1.0f - ly, hx = 1.0f - lx;
+                h8v oh, ol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float o = hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]);
+                    const _Float16 hh = (fabsf(o) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)o;
+                    oh[e] = u_in[dy][dx] ? hh : (_Float16)0.0f;
+                    ol[e] = u_in[dy][dx] ? (_Float16)((o - (float)hh) * 2048.0f) : (_Float16)0.0f;
+                }
+                const int p = (2 * u_ci + dy) * HPW + 2 * u_cj + dx, d = p >> 1, pc = (p & 1) * 8 + u_c8;
+                *reinterpret_cast<h8v*>(lds + d * 256 + ((pc ^ (d & 15)) * 16)) = oh;
+                *reinterpret_cast<h8v*>(lds + d * 256 + (((pc + 4) ^ (d & 15)) * 16)) = ol;
+            }
+    };
     auto issue_b = [&](int g, int ky, int buf) {
         unsigned char* sb = lds + HA_BYTES + buf * B_BYTES + wave * 1024;
         const int soff = (ky * 3 * G + g) * 128;
@@ -433,8 +494,8 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 #pragma unroll
     for (int j = 0; j < TN; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
 
-    issue_a(0);
-    issue_b(0, 0, 0);
+    if constexpr (UP2) { issue_b(0, 0, 0); fill_a(0); }            // (the weights travel while the halo is computed)
+    else               { issue_a(0); issue_b(0, 0, 0); }
     int buf = 0;
     for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -470,7 +531,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
             wait_lds_reads();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue_a(g + 1);
+            if constexpr (UP2) fill_a(g + 1); else issue_a(g + 1);
         }
     }
 
@@ -800,6 +861,31 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
                            n4, Cout, a.splitk, (size_t)rows * Cout, act, a.dst_sh, a.res_f32);
         OMNI_HIP(hipGetLastError());
     }
+    return OMNI_OK;
+}
+
+// dst = act(conv3x3(pad 1)(bilinear 2x up-sampling of src) + bias): F.interpolate(scale 2, align_corners=False) + ConvBnReLU of the
+// decoder (model/spherical_model.py:279-301) in one kernel (conv3x3_halo_sh_kernel<.., UP2>).  src SH [M, Hl, Wl, C], dst [M, 2Hl, 2Wl, Cout]
+// SH (fmt bit 0) or fp32; needs 2Wl % 32 == 0, 2Hl % 4 == 0 (OMNI_ERR_UNSUPPORTED otherwise: run omni_upsample_bilinear_sh +
+// omni_conv2d_sh_f16x3_ws, which give the same bits).
+extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, const float* bias, void* dst, int fmt,
+                                         int M, int Hl, int Wl, int C, int Cout, int act, omni_stream_t stream)
+{
+    if (!src || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_up2_sh: null pointer");
+    if (M <= 0 || Hl <= 0 || Wl <= 0 || C <= 0 || C % 32 || Cout <= 0 || Cout % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_up2_sh: bad shape (channels must be multiples of 32)");
+    const int H = 2 * Hl, W = 2 * Wl;
+    if (W % HT_W || H % 4) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv3x3_up2_sh: the output must be a multiple of 4 rows x 32 columns");
+    if ((long long)M * H * W >= (1ll << 31) || (long long)Cout * 9 * C * 4 >= (1ll << 31))
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv3x3_up2_sh: tensor too large for 32-bit indices");
+    ShConvArgs a;
+    a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = dst; a.dst_sh = fmt & 1; a.res_f32 = 0;
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd;
+    a.M = M; a.H = H; a.W = W; a.C1 = C; a.C2 = 0; a.Cout = Cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = act;
+    a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr;
+    const int grid = M * (H / 4) * (W / HT_W);
+    if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
+    else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, true>), dim3(grid * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, a);
+    OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
 

@@ -266,6 +266,20 @@ class Engine:
         _lib.check(fn(_p(x), _p(y), M, H, Wd, C, Ho, Wo, self._s), "upsample")
         return y
 
+    fuse_up = True             # decoder: up-sampling computed inside the following convolution's halo fill where the shape allows
+
+    def _up_conv(self, x, key, M, H, Wd, C, Cout, act, out_f32=False, out=None):
+        """conv3x3(upsample2x(x)) — `F.interpolate` + the stage's first ConvBnReLU (:279-301); one kernel when the output is a
+        multiple of 4 x 32 pixels (same bits as the two-kernel form)."""
+        Ho, Wo = 2 * H, 2 * Wd
+        if self.sh and self.fuse_up and Wo % 32 == 0 and Ho % 4 == 0:
+            if out is None:
+                out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.load().omni_conv3x3_up2_sh_f16x3(_p(x), _p(self.w[key + ".w16"]), _p(self.w[key + ".b"]), _p(out), 0 if out_f32 else 1,
+                                                             M, H, Wd, C, Cout, act, self._s), "up+conv " + key)
+            return out
+        return self._conv(self._up(x, M, H, Wd, C, Ho, Wo), key, M, Ho, Wo, C, Cout, 3, 1, 1, act, out_f32=out_f32, out=out)
+
     # ------------------------------------------------------------------ network over the patch batch
     def network(self, patches, point_feat, bs, confidence, out=None):
         """patches: planar [bs, N, 3, P, P]; point_feat: NHWC [N or bs*N, P/4, P/4, 64].
@@ -346,8 +360,7 @@ class Engine:
         up = self._up(x, M, P16, P16, 128, P8, P8)
         x = self._conv(up, "de_conv1_0", M, P8, P8, 128, 128, 3, 1, 1, ACT_RELU)
         x = self._conv(x, "de_conv1_1", M, P8, P8, 128, 64, 3, 1, 1, ACT_RELU, x2=layer2, C2=128)
-        up = self._up(x, M, P8, P8, 64, P4, P4)
-        x = self._conv(up, "de_conv2_0", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU)
+        x = self._up_conv(x, "de_conv2_0", M, P8, P8, 64, 64, ACT_RELU)
         x = self._conv(x, "de_conv2_1", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU, x2=layer1, C2=64)
         # The two widest stages move 150-300 MB per tensor at 8 panoramas, more than the 256 MB memory-side cache holds.  Run them a few
         # panoramas at a time (same kernels, same bits: no operator here mixes patches) and part of a chunk's intermediates is still
@@ -357,11 +370,9 @@ class Engine:
         x_in, de4 = x, new(M, P, P, 32)
         for m0, m1 in self._chunks(bs, N, self.tail_chunk):
             Mc = m1 - m0
-            up = self._up(x_in[m0:m1], Mc, P4, P4, 64, P2, P2)
-            x = self._conv(up, "de_conv3_0", Mc, P2, P2, 64, 64, 3, 1, 1, ACT_RELU)
+            x = self._up_conv(x_in[m0:m1], "de_conv3_0", Mc, P4, P4, 64, 64, ACT_RELU)
             x = self._conv(x, "de_conv3_1", Mc, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1[m0:m1], C2=64)
-            up = self._up(x, Mc, P2, P2, 32, P, P)
-            self._conv(up, "de_conv4_0", Mc, P, P, 32, 32, 3, 1, 1, ACT_RELU, out_f32=True, out=de4[m0:m1])
+            self._up_conv(x, "de_conv4_0", Mc, P2, P2, 32, 32, ACT_RELU, out_f32=True, out=de4[m0:m1])
             _lib.check(lib.omni_heads_f32(_p(de4[m0:m1]), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]), ctypes.c_float(self.head_bias[1]),
                                           _p(av[m0:m1]), _p(cv[m0:m1]) if cv is not None else None, Mc, P, 1 if confidence else 0, self._s), "heads")
         self.last = {"de_conv4_0": de4, "layer4": layer4}

@@ -68,6 +68,38 @@ def test_gemm_rows_vs_torch(cfg):
     assert lib.omni_gemm_rows_sh_f16x3(_p(XS), _p(W16R), _p(B), _p(R), _p(out), 0, rows, 1024, N, act, _stream()) == 3    # OMNI_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("cfg", [(3, 16, 16, 64, 64, 1, True), (2, 32, 32, 64, 64, 1, True), (2, 64, 64, 32, 32, 1, False), (1, 2, 16, 96, 32, 0, True),
+                                 (5, 6, 48, 32, 128, 1, False)])
+def test_fused_upsample_conv_equals_the_two_kernels(cfg):
+    """omni_conv3x3_up2_sh_f16x3 (the decoder's F.interpolate + ConvBnReLU in one kernel) against omni_upsample_bilinear_sh +
+    omni_conv2d_sh_f16x3_ws bit for bit, and against float64 torch."""
+    L, lib = _lib()
+    M, Hl, Wl, C, Cout, act, out_sh = cfg
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, Hl, Wl, C, generator=g); w = torch.randn(Cout, C, 3, 3, generator=g) / np.sqrt(9 * C); b = torch.randn(Cout, generator=g)
+    X, B = x.to(DEV), b.to(DEV)
+    W16 = split_weights_f16x3(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()).to(DEV)
+    XS = torch.empty_like(X)
+    assert lib.omni_sh_from_f32(_p(X), _p(XS), ctypes.c_size_t(X.numel()), _stream()) == 0
+    H, W = 2 * Hl, 2 * Wl
+    up = torch.empty((M, H, W, C), device=DEV)
+    assert lib.omni_upsample_bilinear_sh(_p(XS), _p(up), M, Hl, Wl, C, H, W, _stream()) == 0
+    two = torch.empty((M, H, W, Cout), device=DEV)
+    assert lib.omni_conv2d_sh_f16x3_ws(_p(up), None, _p(W16), _p(B), None, _p(two), 1 if out_sh else 0, M, H, W, C, 0, Cout, 3, 3, 1, 1, act,
+                                       1, None, ctypes.c_size_t(0), _stream()) == 0, lib.omni_last_error()
+    one = torch.empty((M, H, W, Cout), device=DEV)
+    assert lib.omni_conv3x3_up2_sh_f16x3(_p(XS), _p(W16), _p(B), _p(one), 1 if out_sh else 0, M, Hl, Wl, C, Cout, act, _stream()) == 0, lib.omni_last_error()
+    assert torch.equal(one, two)
+    if not out_sh:
+        xs_back = torch.empty_like(X)
+        assert lib.omni_sh_to_f32(_p(XS), _p(xs_back), ctypes.c_size_t(X.numel()), _stream()) == 0
+        ref = F.conv2d(F.interpolate(xs_back.cpu().double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False), w.double(), b.double(), padding=1)
+        ref = F.relu(ref) if act == 1 else ref
+        assert (one.cpu().double() - ref.permute(0, 2, 3, 1)).abs().max().item() < 3e-5
+    assert lib.omni_conv3x3_up2_sh_f16x3(_p(XS), _p(W16), _p(B), _p(one), 0, M, Hl, 8, C, Cout, act, _stream()) == 3      # 16 columns: OMNI_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("cfg", [
     # M, H, W, C1, C2, Cout, k, stride, pad, act, res
     (3, 16, 16, 64, 0, 64, 3, 1, 1, 1, True),

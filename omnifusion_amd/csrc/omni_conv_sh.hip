@@ -37,6 +37,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 // ------------------------------------------------------------------ stem: conv 7x7 s2 p3, 3 -> 64, + folded BN + ReLU (f16x3)
 // model/spherical_model.py:254 (conv1, bn1, relu) as an implicit GEMM on the fp16 matrix cores.  K is laid out as
 // (c, ky, kx padded 7 -> 8): one 8-wide MFMA fragment is then 8 CONSECUTIVE input pixels of one (channel, kernel row) — four
-// ds_read_b64 from the fp32 input patch parked in LDS, split into hi/lo on the fly; K = 3*7*8 = 168, padded to 192 = 6
+// 4-byte reads from the input patch parked in LDS as a hi and a lo half image (split once per pixel at load time); K = 3*7*8 = 168, padded to 192 = 6
 // groups of 32 with zero weights.  A block owns an 8-row strip of one patch's output (Po columns in tiles of 16): the 64 x 192
 // pre-split filter bank (48 KiB) is DMA'd into LDS once per block, wave w owns output rows 2w, 2w+1 of the strip.
 // Output: SH [M, Po, Po, 64].
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
                                                          const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char wl[64 * SM_G * 128];
-    __shared__ __attribute__((aligned(16))) float img[3 * SM_IH * SM_IP];
+    __shared__ __attribute__((aligned(16))) _Float16 imh[3 * SM_IH * SM_IP], iml[3 * SM_IH * SM_IP];   // the input patch, split ONCE per pixel
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int strips = Po / SM_TH;
@@ -593,18 +594,32 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
 
     // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
     const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
-    for (int ox0 = ox_first; ox0 < ox_last; ox0 += SM_TW) {
+    // the next tile's input pixels travel (global -> registers) under the current tile's matrix work
+    constexpr int IMG = 3 * SM_IH * SM_IP, IPT = (IMG + 255) / 256;
+    float pre[IPT];
+    auto prefetch = [&](int ox0) {
         const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-        __syncthreads();                                          // the previous tile's fragment reads are done
-        for (int i = t; i < 3 * SM_IH * SM_IP; i += 256) {        // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {                           // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
+            const int i = t + 256 * k;
             const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
             const int iy = iy0 + r, ix = ix0 + q;
-            float v = 0.0f;
-            if (q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) v = src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix];
-            img[i] = v;
+            pre[k] = (i < IMG && q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) ? src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix] : 0.0f;
+        }
+    };
+    prefetch(ox_first);
+    for (int ox0 = ox_first; ox0 < ox_last; ox0 += SM_TW) {
+        __syncthreads();                                          // the previous tile's fragment reads are done
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int i = t + 256 * k;
+            const float x = pre[k];
+            const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+            if (i < IMG) { imh[i] = hh; iml[i] = (_Float16)((x - (float)hh) * 2048.0f); }
         }
         if (ox0 == ox_first) wait_vm<0>();                        // the filter bank has landed
         __syncthreads();
+        if (ox0 + SM_TW < ox_last) prefetch(ox0 + SM_TW);
         f16v acc[2], acc1[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
@@ -612,18 +627,14 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
         for (int g = 0; g < SM_G; ++g)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                const float* ip = img + rowoff[2 * g + kc];
+                // 8 consecutive pixels from an even column: four 4-byte reads per half image (every input pixel serves ~28 fragments and
+                // is split once, at load time)
+                const int ro = rowoff[2 * g + kc];
                 h8v ah, al;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float2 xv = *reinterpret_cast<const float2*>(ip + 2 * u);
-                    const float xs[2] = {xv.x, xv.y};
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const float x = xs[w];
-                        const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
-                        ah[2 * u + w] = hh; al[2 * u + w] = (_Float16)((x - (float)hh) * 2048.0f);
-                    }
+                    const h2v xh = *reinterpret_cast<const h2v*>(imh + ro + 2 * u), xl = *reinterpret_cast<const h2v*>(iml + ro + 2 * u);
+                    ah[2 * u] = xh[0]; ah[2 * u + 1] = xh[1]; al[2 * u] = xl[0]; al[2 * u + 1] = xl[1];
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {

@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 900 python tools/flag_ab.py
+timeout 300 python tools/_stem_ab.py

@@ -190,6 +190,13 @@ int omni_gemm_rows_pack(const void* wt16, void* wt16r, int N, int K, omni_stream
  * 2Wl % 32 == 0 and 2Hl % 4 == 0 (else OMNI_ERR_UNSUPPORTED: omni_upsample_bilinear_sh + omni_conv2d_sh_f16x3_ws give the same bits). */
 int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, const float* bias, void* dst, int fmt,
                               int M, int Hl, int Wl, int C, int Cout, int act, omni_stream_t stream);
+/* omni_conv2d_sh_f16x3_ws with `post` (fp32, post_elems = whole rows of Cout channels) added AFTER the activation, output row index
+ * modulo its row count: `layer1 + point_feat` (model/spherical_model.py:258; point_feat [N,h,w,64] broadcast over the batch, or
+ * full size) inside layer1's last convolution.  post = NULL: the plain operator.  Not combinable with split-K. */
+int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
+                                 const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
+                                 int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                 const float* post, size_t post_elems, omni_stream_t stream);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a

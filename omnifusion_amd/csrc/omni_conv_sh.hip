@@ -93,6 +93,7 @@ struct ShConvArgs {
     int dbg;                                 // debug build only (OMNI_CONV_DBG): 4 = skip the epilogue
     int noxcd;                               // 1: identity block order (tuning, OMNI_CONV_NOXCD)
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
+    const float* post; unsigned post_rows;   // fp32 [post_rows][Cout] added AFTER the activation, row index modulo post_rows (layer1 + point_feat), or null
 };
 
 // Fused epilogue of NT accumulator tiles of ONE pixel row r (D = W x pixels: a lane holds, per register quad q, the four
@@ -103,6 +104,7 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
                                              const int (&c0)[NT], int lane, bool dst_sh)
 {
     f4v bq[NT * 4], rf[NT * 4]; h4v rh[NT * 4], rl[NT * 4];
+    const float* post = a.post ? a.post + (size_t)((unsigned)r % a.post_rows) * a.Cout : nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -131,6 +133,7 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
             }
+            if (post) v += *reinterpret_cast<const f4v*>(post + c);
             const size_t o = r * a.Cout + c;
             if (dst_sh) act_store4<true>(a.dst, o, v);
             else        act_store4<false>(a.dst, o, v);
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
         rowoff[f] = ((rr / 7) * SM_IH + rr % 7 + 2 * py) * SM_IP + 2 * px;
     }
     ShConvArgs e;
-    e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst;
+    e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst; e.post = nullptr; e.post_rows = 1;
 
     // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
     const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
@@ -797,10 +800,24 @@ void launch_sh(const ShConvArgs& a, hipStream_t s)
 // src1/src2: SH tensors; fmt bit 0: dst is SH (else fp32 NHWC); fmt bit 1: res is fp32 NHWC (else SH); wt16 as for
 // omni_conv2d_nhwc_f16x3_ws.  A plain GEMM is the case H = W = KH = KW = 1 (rows = M).
 // Requirements: C1, C2, Cout multiples of 32, kernels up to 3x3.  split-K as in omni_conv2d_nhwc_f32_ws.
+// `post` (or null): fp32 [post_elems / Cout][Cout] added after the activation, output row index modulo its row count — layer1 + point_feat
+// (model/spherical_model.py:258) inside layer1's last convolution instead of a pass of its own.  Not with split-K.
+extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
+                                            const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
+                                            int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                            const float* post, size_t post_elems, omni_stream_t stream);
 extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
                                        const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                        int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                                        omni_stream_t stream)
+{
+    return omni_conv2d_sh_f16x3_post_ws(src1, src2, wt16, bias, res, dst, fmt, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes,
+                                        nullptr, 0, stream);
+}
+extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
+                                            const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
+                                            int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                                            const float* post, size_t post_elems, omni_stream_t stream)
 {
     const int dst_sh = fmt & 1;
     if (!src1 || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: null pointer");
@@ -829,6 +846,13 @@ extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
     a.splitk = S > 1 ? S : 1; a.ws = ws;
+    a.post = post; a.post_rows = 1;
+    if (post) {
+        if (Cout <= 0 || post_elems == 0 || post_elems % (size_t)Cout || post_elems / (size_t)Cout > 0x7fffffffull)
+            OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: the post-activation addend must hold whole rows of Cout channels");
+        if (a.splitk > 1) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv2d_sh: no post-activation addend with split-K");
+        a.post_rows = (unsigned)(post_elems / (size_t)Cout);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % 4 == 0 && !omni_options().conv_nohalo) {
         const int th = (H % 8 == 0 && omni_options().conv_halo_th == 8) ? 8 : 4;
@@ -892,7 +916,7 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
     a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = dst; a.dst_sh = fmt & 1; a.res_f32 = 0;
     a.dbg = 0; a.noxcd = omni_options().conv_noxcd;
     a.M = M; a.H = H; a.W = W; a.C1 = C; a.C2 = 0; a.Cout = Cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = act;
-    a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr;
+    a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
     const int grid = M * (H / 4) * (W / HT_W);
     if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
     else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, true>), dim3(grid * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, a);

@@ -161,7 +161,7 @@ class Engine:
         return bool(flag.value)
 
     # ------------------------------------------------------------------ operator shims
-    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True, out_f32=False, out=None):
+    def _conv(self, x, key, M, H, Wd, C1, Cout, k, stride, pad, act, x2=None, C2=0, res=None, bias=True, out_f32=False, out=None, post=None):
         """One convolution (+ folded BN, bias, residual, activation).  In the f16x3 mode the activations x, x2, res and
         the result are split-half (SH) tensors (csrc/omni_sh.h) unless out_f32 asks for a plain fp32 NHWC result."""
         lib = _lib.load()
@@ -171,7 +171,11 @@ class Engine:
             out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
         b = _p(self.w[key + ".b"]) if bias else None
-        if self.sh:
+        if self.sh and post is not None:                            # `+ post` after the activation, inside the epilogue (SH mode, never split)
+            rc = lib.omni_conv2d_sh_f16x3_post_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), 0 if out_f32 else 1,
+                                                  M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb),
+                                                  _p(post), ctypes.c_size_t(post.numel()), self._s)
+        elif self.sh:
             rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), 0 if out_f32 else 1,
                                              M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         else:
@@ -266,6 +270,7 @@ class Engine:
         _lib.check(fn(_p(x), _p(y), M, H, Wd, C, Ho, Wo, self._s), "upsample")
         return y
 
+    fold_point_feat = True     # `layer1 + point_feat` inside layer1's last convolution (one rounding to the SH format instead of two: results move by ~1e-7)
     fuse_up = True             # decoder: up-sampling computed inside the following convolution's halo fill where the shape allows
 
     def _up_conv(self, x, key, M, H, Wd, C, Cout, act, out_f32=False, out=None):
@@ -316,9 +321,10 @@ class Engine:
                     ident = self._conv(x, p + ".ds", M, size, size, cin, cout, 1, s, 0, ACT_NONE)
                 y = self._conv(x, p + ".c1", M, size, size, cin, cout, 3, s, 1, ACT_RELU)
                 size = (size + 2 - 3) // s + 1
-                x = self._conv(y, p + ".c2", M, size, size, cout, cout, 3, 1, 1, ACT_RELU, res=ident)
+                fold = sh and self.fold_point_feat and lname == "layer1" and i == nblk - 1     # layer1 + point_feat (:258) in the block's last epilogue
+                x = self._conv(y, p + ".c2", M, size, size, cout, cout, 3, 1, 1, ACT_RELU, res=ident, post=point_feat if fold else None)
                 cin = cout
-            if lname == "layer1":                                   # layer1 + point_feat (:258)
+            if lname == "layer1" and not (sh and self.fold_point_feat):                          # ... or as a pass of its own
                 _lib.check((lib.omni_add_period_sh if sh else lib.omni_add_period_f32)(
                     _p(x), _p(point_feat), ctypes.c_size_t(x.numel()), ctypes.c_size_t(point_feat.numel()), self._s), "add point_feat")
             feats[lname] = x

@@ -100,6 +100,35 @@ def test_fused_upsample_conv_equals_the_two_kernels(cfg):
     assert lib.omni_conv3x3_up2_sh_f16x3(_p(XS), _p(W16), _p(B), _p(one), 0, M, Hl, 8, C, Cout, act, _stream()) == 3      # 16 columns: OMNI_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("cfg", [(6, 32, 32, 64, 64, 3), (4, 16, 16, 128, 128, 4), (2, 8, 8, 64, 64, 2)])
+def test_conv_with_post_activation_addend(cfg):
+    """omni_conv2d_sh_f16x3_post_ws: relu(conv + bias + res) + post[row % rows_of_post] (layer1 + point_feat folded into the epilogue)
+    against float64 torch, on the halo kernel (32-column images) and the tile kernel."""
+    L, lib = _lib()
+    M, H, W, C, Cout, per = cfg                       # post holds `per` images, broadcast over the M images
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, H, W, C, generator=g); w = torch.randn(Cout, C, 3, 3, generator=g) / np.sqrt(9 * C); b = torch.randn(Cout, generator=g)
+    res = torch.randn(M, H, W, Cout, generator=g); post = torch.randn(per, H, W, Cout, generator=g)
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double())
+    ref = ref + post.double().repeat((M + per - 1) // per, 1, 1, 1)[:M]
+    X, B, R, PO = x.to(DEV), b.to(DEV), res.to(DEV), post.to(DEV)
+    W16 = split_weights_f16x3(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()).to(DEV)
+    XS, RS = torch.empty_like(X), torch.empty_like(R)
+    assert lib.omni_sh_from_f32(_p(X), _p(XS), ctypes.c_size_t(X.numel()), _stream()) == 0
+    assert lib.omni_sh_from_f32(_p(R), _p(RS), ctypes.c_size_t(R.numel()), _stream()) == 0
+    out = torch.empty((M, H, W, Cout), device=DEV)
+    rc = lib.omni_conv2d_sh_f16x3_post_ws(_p(XS), None, _p(W16), _p(B), _p(RS), _p(out), 0, M, H, W, C, 0, Cout, 3, 3, 1, 1, 1, 1, None, ctypes.c_size_t(0),
+                                          _p(PO), ctypes.c_size_t(PO.numel()), _stream())
+    assert rc == 0, lib.omni_last_error()
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5
+    ws = torch.empty(2 * out.numel(), device=DEV)
+    assert lib.omni_conv2d_sh_f16x3_post_ws(_p(XS), None, _p(W16), _p(B), _p(RS), _p(out), 0, M, H, W, C, 0, Cout, 3, 3, 1, 1, 1, 2, _p(ws),
+                                            ctypes.c_size_t(ws.numel() * 4), _p(PO), ctypes.c_size_t(PO.numel()), _stream()) == 3      # no addend with split-K
+    assert lib.omni_conv2d_sh_f16x3_post_ws(_p(XS), None, _p(W16), _p(B), _p(RS), _p(out), 0, M, H, W, C, 0, Cout, 3, 3, 1, 1, 1, 1, None, ctypes.c_size_t(0),
+                                            _p(PO), ctypes.c_size_t(PO.numel() - 1), _stream()) == 1
+
+
 @pytest.mark.parametrize("cfg", [
     # M, H, W, C1, C2, Cout, k, stride, pad, act, res
     (3, 16, 16, 64, 0, 64, 3, 1, 1, 1, True),

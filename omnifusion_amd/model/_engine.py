@@ -368,9 +368,7 @@ class Engine:
         x = self._conv(x, "de_conv1_1", M, P8, P8, 128, 64, 3, 1, 1, ACT_RELU, x2=layer2, C2=128)
         x = self._up_conv(x, "de_conv2_0", M, P8, P8, 64, 64, ACT_RELU)
         x = self._conv(x, "de_conv2_1", M, P4, P4, 64, 64, 3, 1, 1, ACT_RELU, x2=layer1, C2=64)
-        # The two widest stages move 150-300 MB per tensor at 8 panoramas, more than the 256 MB memory-side cache holds.  Run them a few
-        # panoramas at a time (same kernels, same bits: no operator here mixes patches) and part of a chunk's intermediates is still
-        # cached when their consumer starts — a small effect (+1.3 % with three forwards in flight), these layers are not purely HBM-bound.
+        # the two widest stages, optionally a few panoramas at a time (Engine.tail_chunk; no operator here mixes patches)
         a, c = out if out is not None else (new(bs, N, 1, P, P), new(bs, N, 1, P, P) if confidence else None)
         av, cv = a.view(M, P, P), c.view(M, P, P) if c is not None else None
         x_in, de4 = x, new(M, P, P, 32)
@@ -384,9 +382,10 @@ class Engine:
         self.last = {"de_conv4_0": de4, "layer4": layer4}
         return a, c
 
-    # measured interleaved (tools/chunk_ab.py, 8 panoramas, 3 forwards in flight): tail 4 +1.2..1.4 %, tail 2 the same, tail 1 -2 %; the
-    # front (stem -> max-pool) gains nothing; plain calls (two 4-panorama lanes) are unchanged by 4 and lose 1.6 % with 2
-    tail_chunk = 4             # panoramas per pass through the decoder's two widest stages (0: the whole batch at once)
+    # Passes of a few panoramas through the widest stages (same kernels, same bits) were worth +1.3 % with three forwards in flight while the
+    # up-sampled tensors still went through HBM; since the up-sampling is computed inside the convolution (fuse_up) they change nothing
+    # (tools/chunk_ab.py: 3515 vs 3517 panoramas/s), so the default is the whole batch at once.
+    tail_chunk = 0             # panoramas per pass through the decoder's two widest stages (0: the whole batch at once)
     front_chunk = 0            # ... and through stem -> max-pool
 
     @staticmethod

@@ -1312,6 +1312,15 @@ extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dty
     if (B == 0 || C == 0) return OMNI_OK;
     if (!grad_pers || !grad_erp) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers_bwd: null device pointer");
     E2PArgs a; fill_args(a, g, grad_erp, const_cast<void*>(grad_pers), B, C);
+    {   // first backward of this geometry: build its tables (synchronises the stream once)
+        omni_geometry* gm = const_cast<omni_geometry*>(g);
+        std::lock_guard<std::mutex> lk(gm->bwd_mu);
+        if (!gm->e2p_bwd_tried) {
+            gm->e2p_bwd_tried = 1;
+            rc = omni_e2p_build_bwd(gm, (hipStream_t)stream);
+            if (rc != OMNI_OK) return rc;
+        }
+    }
     const int mode = omni_options().e2p_bwd_simple;
     // mode 0 (default): whichever is faster for the layout — measured at B = 8, cfg 1: planar 0.74 ms (LDS boxes + coalesced global atomics) vs
     // 0.88 ms (gathers); reference layout 0.88 ms (gathers) vs 3.17 ms (plain scatter).  3 forces the gathers, 1 the plain scatter, 2 the LDS boxes.

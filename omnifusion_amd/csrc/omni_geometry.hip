@@ -203,10 +203,8 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
         OMNI_HIP(hipMemcpy(g->col_trig, ct.data(), sizeof(float2) * W, hipMemcpyHostToDevice));
         int rc = omni_p2e_build_candidates(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_p2e_build_tiles(g.get(), stream);
-        if (rc == OMNI_OK) rc = omni_p2e_build_bwd(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_tileflags(g.get(), stream);
         if (rc == OMNI_OK) rc = omni_e2p_build_boxes(g.get(), stream);
-        if (rc == OMNI_OK) rc = omni_e2p_build_bwd(g.get(), stream);
         if (rc != OMNI_OK) { omni_geometry_destroy(g.release()); return rc; }
     }
     *out = g.release();

@@ -1,5 +1,6 @@
 // omni_internal.h — shared host/device declarations of libomnifusion_hip.so (gfx950 only).
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -95,6 +96,8 @@ struct omni_geometry {
     float2* e2p_ixy;               // equi2pers: clamped sampling coordinates (ix, iy) of every patch sample [N][ph][pw]
     // equi2pers backward by gathers (omni_equi2pers.hip): per (4 x 32 ERP tile, patch) the box of the patch samples whose taps touch the tile
     int4* e2p_bwd_box; int* e2p_bwd_ids; int e2p_bwd_nsmall, e2p_bwd_nbig, e2p_gtx, e2p_gty, e2p_bwd_ok;
+    // the two backward tables are built by the FIRST backward call of the geometry (3.7 ms of one-time kernels a forward-only user never pays)
+    std::mutex bwd_mu; int p2e_bwd_tried = 0, e2p_bwd_tried = 0;
 };
 
 // implemented in omni_geometry.hip

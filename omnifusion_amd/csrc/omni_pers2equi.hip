@@ -1014,6 +1014,15 @@ extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dty
     P2EArgs a;
     rc = fill_args(a, g, grad_pers, nullptr, const_cast<void*>(grad_erp), B, C, layout);
     if (rc != OMNI_OK) return rc;
+    {   // first backward of this geometry: build its tables (synchronises the stream once)
+        omni_geometry* gm = const_cast<omni_geometry*>(g);
+        std::lock_guard<std::mutex> lk(gm->bwd_mu);
+        if (!gm->p2e_bwd_tried) {
+            gm->p2e_bwd_tried = 1;
+            rc = omni_p2e_build_bwd(gm, (hipStream_t)stream);
+            if (rc != OMNI_OK) return rc;
+        }
+    }
     if (g->p2e_bwd_ok && !omni_options().p2e_bwd_simple) {
         constexpr int PL = 4;
         const int groups = (B * C + PL - 1) / PL;

@@ -761,7 +761,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
             dst += plane;
             if (++cc == a.C) { cc = 0; dst += bskip; }
         };
-        // groups of NB stages (planes % NB == 0, host-checked).  vmcnt counts, per stage s of a group (in-order completion; the ONE
+        // groups of NB stages, then planes % NB single stages (NB <= planes, host-checked).  vmcnt counts, per stage s of a group (in-order completion; the ONE
         // store of a stage counts like a DMA piece):  first group  (NB-1) NJ + s   |  middle  (NB-1)(1 + NJ)
         //                                             last group   (NB-1) + (NB-1-s) NJ   |  only group  (NB-1-s) NJ + s
         const int groups = planes / NB;
@@ -783,6 +783,12 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
             group(std::integral_constant<int, 0>(), 0);
             for (int gi = 1; gi + 1 < groups; ++gi) group(std::integral_constant<int, 1>(), gi * NB);
             group(std::integral_constant<int, 2>(), (groups - 1) * NB);
+        }
+        for (int p = groups * NB; p < planes; ++p) {             // an odd plane count (3 planes of ONE panorama): the rest, one stage at a time
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue(p, 0);
+            e2b_wait_vm<0>();
+            consume(0);
         }
     };
     switch (njj) {
@@ -1066,12 +1072,12 @@ int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, size_t tensor
 template <typename T>
 int launch_e2b(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t tensor_bytes, hipStream_t stream)
 {
-    // stages in flight: 1, 2 or 4 (option e2p_nbuf), a divisor of the plane count (the stage loop runs in groups of NB)
+    // stages in flight: 1, 2 or 4 (option e2p_nbuf), at most the plane count (the stage loop runs in groups of NB, the remainder singly)
     const int planes = B * C;
     int nb = omni_options().e2p_nbuf;
     if (nb <= 0) nb = 2;                               // (4 stages in flight measured slower: 41.5 vs 38.3 us at B = 8, 18 x 256^2)
-    if (nb >= 4 && planes % 4 == 0) return launch_e2b_nb<T, 4>(a, g, B, tensor_bytes, stream);
-    if (nb >= 2 && planes % 2 == 0) return launch_e2b_nb<T, 2>(a, g, B, tensor_bytes, stream);
+    if (nb >= 4 && planes >= 4) return launch_e2b_nb<T, 4>(a, g, B, tensor_bytes, stream);
+    if (nb >= 2 && planes >= 2) return launch_e2b_nb<T, 2>(a, g, B, tensor_bytes, stream);
     return launch_e2b_nb<T, 1>(a, g, B, tensor_bytes, stream);
 }
 

@@ -384,7 +384,7 @@ constexpr int p2e_slots(int pieces, int nbmax, int pl)
 
 template <typename T, int PL, bool CONF, int NBMAX>
 __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_y,
-                                                        unsigned tensor_bytes)
+                                                        unsigned tensor_bytes, int p_first)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char p2e_smem[];        // the ONLY LDS object of this kernel
     constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = P2E_NPX;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     const int col = lane & 31, rsub = lane >> 5;
     const int j = tj * P2E_TW + col;
     const bool jin = j < a.W;
-    const int p_begin = (int)blockIdx.y * PL;
+    const int p_begin = p_first + (int)blockIdx.y * PL;
     unsigned char* const ring = p2e_smem;
     const p2e_rsrc_t rs1 = p2e_make_rsrc(a.pers, tensor_bytes);
     const p2e_rsrc_t rs2 = p2e_make_rsrc(CONF ? a.pers2 : a.pers, tensor_bytes);
@@ -647,37 +647,45 @@ void launch_p2e_pl(const P2EArgs& a, int planes, int rows4, int nblocks, hipStre
 // ---- LDS path: launch geometry.  One wave per (tile, group of PL planes); LDS per wave = the ring (or the largest stage of the
 // geometry if that is larger); option "p2e_nbuf" caps the stages in flight (tuning).
 template <typename T, int PL, bool CONF, int NBMAX>
-int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
+int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int p_first, int planes, size_t tensor_bytes, hipStream_t stream)
 {
     const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
     const int stage_kb = (tt.max_chunks + 63) / 64 * (CONF ? 2 : 1);
     const size_t lds = (size_t)(stage_kb > P2E_RING_KB ? stage_kb : P2E_RING_KB) * 1024;
     hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NBMAX>), dim3(omni_xcd_rows_grid(g->p2e_ty, g->p2e_tx), planes / PL), dim3(64), lds, stream, a,
-                       (const uint2*)tt.ent, g->p2e_tx, g->p2e_ty, (unsigned)tensor_bytes);
+                       (const uint2*)tt.ent, g->p2e_tx, g->p2e_ty, (unsigned)tensor_bytes, p_first);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
 
 template <typename T, int PL, bool CONF>
-int launch_p2e_lds_pl(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
+int launch_p2e_lds_pl(const P2EArgs& a, const omni_geometry* g, int p_first, int planes, size_t tensor_bytes, hipStream_t stream)
 {
     int nb = omni_options().p2e_nbuf;
     if (nb <= 0) nb = 2;   // measured: 2 stages x 16 waves/CU beat 4 stages (18.4 vs 19.3 us at B=8 18x256^2)
-    if (nb >= 4) return launch_p2e_lds_nb<T, PL, CONF, 4>(a, g, planes, tensor_bytes, stream);
-    if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, planes, tensor_bytes, stream);
-    return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, planes, tensor_bytes, stream);
+    if (nb >= 4) return launch_p2e_lds_nb<T, PL, CONF, 4>(a, g, p_first, planes, tensor_bytes, stream);
+    if (nb >= 2) return launch_p2e_lds_nb<T, PL, CONF, 2>(a, g, p_first, planes, tensor_bytes, stream);
+    return launch_p2e_lds_nb<T, PL, CONF, 1>(a, g, p_first, planes, tensor_bytes, stream);
 }
 
 template <typename T, bool CONF>
 int launch_p2e_lds(const P2EArgs& a, const omni_geometry* g, int planes, size_t tensor_bytes, hipStream_t stream)
 {
-    // planes per wave: the largest of 8, 4, 2, 1 that divides the plane count (the tap geometry is evaluated once per wave and
-    // patch and amortised over them); the groups go to blockIdx.y
+    // planes per wave: 8, 4, 2 or 1 (the tap geometry is evaluated once per wave and patch and amortised over them); the groups go to
+    // blockIdx.y.  A plane count that is not a multiple of 8 runs as up to four launches over consecutive plane ranges (7 = 4 + 2 + 1)
+    // instead of falling to one plane per wave, where the geometry is as much work as the blend.
     const int cap = omni_options().p2e_planes > 0 ? omni_options().p2e_planes : (CONF ? 4 : 8);   // (CONF, 8 planes: 2 x 16 accumulators spill at 128 VGPRs)
-    if (planes % 8 == 0 && cap >= 8) return launch_p2e_lds_pl<T, 8, CONF>(a, g, planes, tensor_bytes, stream);
-    if (planes % 4 == 0 && cap >= 4) return launch_p2e_lds_pl<T, 4, CONF>(a, g, planes, tensor_bytes, stream);
-    if (planes % 2 == 0 && cap >= 2) return launch_p2e_lds_pl<T, 2, CONF>(a, g, planes, tensor_bytes, stream);
-    return launch_p2e_lds_pl<T, 1, CONF>(a, g, planes, tensor_bytes, stream);
+    int p = 0;
+    while (p < planes) {
+        const int left = planes - p;
+        int rc;
+        if (left >= 8 && cap >= 8)      { const int n = left / 8 * 8; rc = launch_p2e_lds_pl<T, 8, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
+        else if (left >= 4 && cap >= 4) { const int n = left / 4 * 4; rc = launch_p2e_lds_pl<T, 4, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
+        else if (left >= 2 && cap >= 2) { const int n = left / 2 * 2; rc = launch_p2e_lds_pl<T, 2, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
+        else                            { rc = launch_p2e_lds_pl<T, 1, CONF>(a, g, p, left, tensor_bytes, stream); p += left; }
+        if (rc != OMNI_OK) return rc;
+    }
+    return OMNI_OK;
 }
 
 template <typename T, bool CONF>

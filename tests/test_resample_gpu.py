@@ -271,7 +271,9 @@ def test_high_res_config5_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("cfg", [(8, 3, 512, 1024, 4, 256, "float32"), (2, 3, 512, 1024, 4, 128, "float32"), (1, 2, 1024, 2048, 6, 256, "float32"),
-                                 (2, 3, 256, 512, 5, 64, "float16"), (3, 2, 200, 336, 3, 64, "float32"), (5, 1, 128, 256, 4, 32, "float16")])
+                                 (2, 3, 256, 512, 5, 64, "float16"), (3, 2, 200, 336, 3, 64, "float32"), (5, 1, 128, 256, 4, 32, "float16"),
+                                 (7, 1, 256, 512, 4, 64, "float32"), (1, 3, 256, 512, 4, 128, "float32"), (5, 3, 128, 256, 4, 32, "float32"),
+                                 (11, 1, 128, 256, 4, 32, "float32")])      # plane counts 7, 3, 15, 11: several launches / single trailing stages
 def test_lds_and_gather_paths_give_the_same_bits(cfg):
     """The LDS-staged kernels (e2p_box_kernel, p2e_lds_kernel) and the direct-gather kernels evaluate the same tap functions and the
     same sums in the same order: torch.equal, whatever the tile/box decomposition (options e2p_gather / p2e_gather select the path)."""

@@ -563,6 +563,36 @@ def test_geometry_cache_is_bounded():
         lib.omni_geometry_cache_clear()
 
 
+def test_engine_switches_are_result_neutral():
+    """The engine's execution switches: fused up-sampling and passes of a few panoramas through the widest stages change no bit;
+    the folded `layer1 + point_feat` and the lone panorama's register-streaming GEMMs change the result by rounding only."""
+    from omnifusion_amd.model._engine import Engine
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    net_it = spherical_fusion_it(4, 18, (128, 128), (80, 80)).cuda()
+    net_it.load_state_dict(make_state_dict(42, 18, True))
+    rgb = torch.rand((3, 3, 128, 256), generator=torch.Generator().manual_seed(31)).to(DEV)
+    one = rgb[:1].contiguous()
+    defaults = {k: getattr(Engine, k) for k in ("fuse_up", "tail_chunk", "front_chunk", "fold_point_feat", "rows_gemm")}
+    ref, ref1, ref_it = net(rgb, confidence=True).clone(), net(one, confidence=True).clone(), net_it(rgb, 2)[-1].clone()
+    try:
+        for name, value, exact in (("fuse_up", False, True), ("tail_chunk", 1, True), ("tail_chunk", 2, True), ("front_chunk", 1, True),
+                                   ("fold_point_feat", False, False), ("rows_gemm", False, False)):
+            setattr(Engine, name, value)
+            out, out1, out_it = net(rgb, confidence=True), net(one, confidence=True), net_it(rgb, 2)[-1]
+            if exact:
+                assert torch.equal(out, ref) and torch.equal(out1, ref1) and torch.equal(out_it, ref_it), name
+            else:
+                assert (out - ref).abs().max().item() < 2e-5 and (out1 - ref1).abs().max().item() < 2e-5 and (out_it - ref_it).abs().max().item() < 2e-5, name
+                if name == "rows_gemm":
+                    assert torch.equal(out, ref), "the rows GEMM is for a lone panorama only"
+            setattr(Engine, name, defaults[name])
+    finally:
+        for k, v in defaults.items():
+            setattr(Engine, k, v)
+
+
 def test_pipelined_forwards_give_the_bits_of_plain_calls():
     """`net.pipelined(depth)`: several complete forwards in flight on several streams (private execution contexts) — same bits
     as one call after the other, also for the iterative model and across a weight reload"""

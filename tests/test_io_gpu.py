@@ -99,3 +99,18 @@ def test_device_feeder_with_a_consumer_on_other_streams():
         pend.append(p)
     got = [p.get() for p in pend]
     assert len(got) == 9 and all(torch.equal(g, w) for g, w in zip(got, want))
+
+
+@pytest.mark.parametrize("extra", [[], ["--iterative", "--iter", "2"], ["--depth", "1", "--src-scale", "2"]])
+def test_eval_harness_runs_end_to_end(tmp_path, extra):
+    """tools/eval.py (the loop of test.py:193-258: loader -> forward -> on-device metrics -> PLY) on synthetic Stanford2D3D-shaped frames:
+    finishes, prints the seven averages and writes a point cloud."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "eval.py"), "--batches", "3", "--batch", "2", "--height", "128", "--width", "256",
+           "--ply-every", "2", "--out", str(tmp_path)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Avg. Abs. Rel. Error" in r.stdout and "panoramas/s" in r.stdout, r.stdout[-1000:]
+    assert any(f.endswith(".ply") for _, _, fs in os.walk(tmp_path) for f in fs)

@@ -40,7 +40,15 @@ for name, H, W, C1, C2, Cout, k, s, pad, use_res in CFGS:
                 if tname == "x1": x1 = o_
                 elif tname == "x2": x2 = o_
                 else: res = o_
+    fused_up = SH and os.environ.get("FUSED_UP", "1") == "1" and name in ("de2_0", "de3_0", "de4_0")    # as the model runs them: up-sampling inside the kernel
+    if fused_up:
+        xl = torch.randn(M, H // 2, W // 2, C1, device="cuda"); xls = torch.empty_like(xl)
+        lib.omni_sh_from_f32(P(xl), P(xls), ctypes.c_size_t(xl.numel()), S())
     def run():
+        if fused_up:
+            rc = lib.omni_conv3x3_up2_sh_f16x3(P(xls), P(w16), P(b), P(out), 1, M, H // 2, W // 2, C1, Cout, 1, S())
+            assert rc == 0, lib.omni_last_error()
+            return
         if SH:
             rc = lib.omni_conv2d_sh_f16x3_ws(P(x1), P(x2), P(w16), P(b), P(res), P(out), 1, M, H, W, C1, C2, Cout, k, k, s, pad, 1,
                                              sk, P(ws), ctypes.c_size_t(ws.numel() * 4), S())

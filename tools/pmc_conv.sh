@@ -1,0 +1,35 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/pmc_conv.sh <tag>  -> gpurun_out/<tag>_conv_pmc.txt
+# MFMA utilisation of the network's convolution kernels: rocprofv3 --kernel-trace --pmc (two separate passes, no other trace domain) on
+# tools/convbench.py (every convolution shape of the network at 8 panoramas = 144 patches, f16x3 SH path, the decoder's first convolutions
+# with the up-sampling inside).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the SIMD-cycles
+# of the launch in which a matrix instruction was executing (32 cycles per v_mfma_f32_32x32x16_f16).
+tag=$1
+out=$GRAFT_REPO_ROOT/gpurun_out/pmcc_$tag; rm -rf $out; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  i=$((i+1))
+  timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o p$i -- python $GRAFT_REPO_ROOT/tools/convbench.py > $out/p$i.log 2>&1
+done
+python - > $GRAFT_REPO_ROOT/gpurun_out/${tag}_conv_pmc.txt <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
+for f in glob.glob("$out/p*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:78]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob("$out/p*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        dur[r["Kernel_Name"][:78]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("# snapshot $tag — rocprofv3 --kernel-trace --pmc <set> (2 separate passes, tools/pmc_conv.sh) on tools/convbench.py: every convolution shape of the")
+print("# network at 8 panoramas (144 patches), f16x3 SH path; means per dispatch over the shapes a kernel form serves.")
+print("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): share of the launch's SIMD-cycles with a matrix instruction executing")
+for k, d in sorted(agg.items(), key=lambda kv: -sum(dur[kv[0]])):
+    if "conv" not in k: continue
+    m = lambda c: sum(d[c]) / len(d[c]) if c in d else float("nan")
+    print("%s avg_us=%.1f n=%d   mfma_busy=%.1f%%" % (k, sum(dur[k]) / len(dur[k]), len(dur[k]), 100 * m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)))
+    for c, v in sorted(d.items()):
+        print(f"   {c:40s} mean={sum(v)/len(v):.4g}")
+PY
+head -30 $GRAFT_REPO_ROOT/gpurun_out/${tag}_conv_pmc.txt

@@ -38,6 +38,8 @@ struct E2PArgs {
     float sx_scale, sy_scale;  // (W-1)/2, (H-1)/2  (grid_sample align_corners=True)
     int dbg;                   // tuning hook (OMNI_E2P_DBG): 1 = suppress stores, 2 = suppress box loads
     const float2* ixy;         // per-geometry table of clamped sampling coordinates [N][ph][pw] (e2p_lds_kernel), or null
+    long long* trace;          // debug build, OMNI_E2P_DBG bit 16: per-block time stamps (omni_debug_set_trace)
+    int store_mode;            // option e2p_store: 0 plain | 1 nt | 2 sc1 (write-through, line dropped from the XCD's L2) | 3 sc0 sc1
     PatchTab tab;
 };
 
@@ -622,33 +624,50 @@ __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __rest
 template <typename T> struct E2BStore4;
 template <> struct E2BStore4<float> {
     static __device__ __forceinline__ void st(float* p, const float (&r)[4]) { *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]); }
+    // cache-policy variants of the same 16-byte store (MI355X_MICROARCH.md, "stores of each flavour": plain / nt keep the line in the
+    // XCD's L2, sc1 writes through and drops it — the output is never re-read by this kernel, the ERP boxes are)
+    static __device__ __forceinline__ void st_mode(float* p, const float (&r)[4], int mode)
+    {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = {r[0], r[1], r[2], r[3]};
+        if (mode == 1)      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    }
 };
 template <> struct E2BStore4<__half> {
     static __device__ __forceinline__ void st(__half* p, const float (&r)[4])
     { __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]); uint2 v; v.x = *reinterpret_cast<unsigned*>(&lo); v.y = *reinterpret_cast<unsigned*>(&hi); *reinterpret_cast<uint2*>(p) = v; }
+    static __device__ __forceinline__ void st_mode(__half* p, const float (&r)[4], int mode)
+    {
+        __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]);
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u v = {*reinterpret_cast<unsigned*>(&lo), *reinterpret_cast<unsigned*>(&hi)};
+        if (mode == 1)      asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        else if (mode == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else if (mode == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    }
 };
 
 template <typename T, int NBMAX, bool ROWMAP>
-__global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* __restrict__ tiles, int tiles_x, int tiles_pp,
-                                                        const int* __restrict__ fb, int nfb_blocks, const int* __restrict__ order, int lds_start,
-                                                        unsigned tensor_bytes)
+__global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* __restrict__ work, int tiles_x, int tiles_pp, unsigned tensor_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char e2b_smem[];        // the ONLY LDS object of this kernel
     constexpr int EPC = 16 / (int)sizeof(T), NPX = E2B_NPX;
     const int lane = threadIdx.x;
-    // grid: [0, nfb_blocks) one block per (listed tile, batch item), direct gathers — FIRST, so that these latency-bound stragglers
-    // run under the streaming blocks instead of after them; [lds_start, ..) the LDS tiles in `order`: block lds_start + k runs on
-    // XCD k % 8 (lds_start is a multiple of 8) and order[k] is a tile of ERP longitude sector k % 8, so that the tiles of ALL
-    // patches that read one region of the panorama share one L2 (an ERP pixel is sampled by 2.1 patches on average)
-    const bool fb_block = (int)blockIdx.x < nfb_blocks;
-    int wid, fb_b = 0;
-    if (fb_block) { wid = fb[blockIdx.x / a.B]; fb_b = blockIdx.x % a.B; }
-    else {
-        if ((int)blockIdx.x < lds_start) return;                   // alignment padding
-        wid = order[(int)blockIdx.x - lds_start];
-        if (wid < 0) return;                                       // sector padding
-    }
-    const uint2 e = tiles[wid];                                    // wave-uniform address: scalar load
+    long long tr0 = 0, tr1 = 0;
+    if (OMNI_DBG(a, 16)) tr0 = wall_clock64();
+    // block -> (tile, plane range): the work table of this (geometry, plane count), e2p_work_table().  x = tile | gather flag << 31,
+    // y = first plane | planes << 16, (z, w) = the tile's box entry.  Block b runs on XCD b % 8 and the table keeps the tiles of one
+    // ERP region on one XCD (an ERP pixel is sampled by 2.1 patches on average; only tiles on ONE XCD share an L2).
+    const uint4 wk = work[blockIdx.x];                             // wave-uniform address: scalar load
+    const int np = (int)(wk.y >> 16), p_start = (int)(wk.y & 0xffffu);
+    if (np == 0) return;                                           // padding
+    const bool fb_block = (wk.x >> 31) != 0;
+    const int wid = (int)(wk.x & 0x7fffffffu);
+    const uint2 e = make_uint2(wk.z, wk.w);
     const int n = wid / tiles_pp, t = wid - n * tiles_pp;
     const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
     const int W = a.W, H = a.H;
@@ -690,15 +709,17 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
     const size_t img_plane = (size_t)H * W;
     const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
     // ROWMAP: after the quad transpose lane l holds row hb + 2 (l % 4), columns 4 ((l % 32) / 4) .. +3 of the tile
-    T* out = (T*)a.pers + (size_t)n * a.C * plane + (ROWMAP ? (size_t)(hb + 2 * (lane & 3)) * a.pw + tw0 + 4 * ((lane & 31) >> 2) : (size_t)hb * a.pw + w);
-    const int planes = a.B * a.C;
+    const int b0 = p_start / a.C, c0p = p_start - b0 * a.C;        // batch item / channel of my first plane
+    T* out = (T*)a.pers + (size_t)b0 * out_bstride + ((size_t)n * a.C + c0p) * plane +
+             (ROWMAP ? (size_t)(hb + 2 * (lane & 3)) * a.pw + tw0 + 4 * ((lane & 31) >> 2) : (size_t)hb * a.pw + w);
+    const size_t bskip = out_bstride - (size_t)a.C * plane;
 
     if (fb_block) {
-        // ---- direct gathers (same taps, same fma chain) for one batch item of a tile whose box does not fit a slot
-        const T* erp = (const T*)a.erp;
-        T* dstb = out + (size_t)fb_b * out_bstride;
-        for (int c = 0; c < a.C; ++c) {
-            const T* img = erp + ((size_t)fb_b * a.C + c) * img_plane;
+        // ---- direct gathers (same taps, same fma chain) for a tile whose box does not fit a slot: planes [p_start, p_start + np)
+        const T* img = (const T*)a.erp + (size_t)p_start * img_plane;
+        T* dstb = out;
+        int cc = c0p;
+        for (int p = 0; p < np; ++p) {
             float r[NPX];
 #pragma unroll
             for (int k = 0; k < NPX; ++k) {
@@ -709,15 +730,17 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
                 r[k] = e2p_blend(v00, v01, v10, v11, w00[k], w01[k], w10[k], w11[k]);
             }
             if (ROWMAP) e2b_quad_transpose(r, lane);
-            E2BStore4<T>::st(dstb + (size_t)c * plane, r);
+            E2BStore4<T>::st(dstb, r);
+            img += img_plane; dstb += plane;
+            if (++cc == a.C) { cc = 0; dstb += bskip; }
         }
         return;
     }
     // every ordinary load has been consumed (the taps depend on them): nothing but LDS-DMA pieces and stores below
+    if (OMNI_DBG(a, 16)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr1 = wall_clock64(); }
     const e2b_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.erp), (short)0, (int)tensor_bytes, 0x00020000);
     const unsigned rowb = (unsigned)W * (unsigned)sizeof(T), planeb = (unsigned)img_plane * (unsigned)sizeof(T);
     const int nchunk = bw4 * bh, njj = (nchunk + 63) >> 6;
-    const size_t bskip = out_bstride - (size_t)a.C * plane;
 
     auto run = [&]<int NJ>(std::integral_constant<int, NJ>) {
         // ring of E2B_RING_KB 1-KiB pieces per wave: a box of NJ pieces gets NB = min(NBMAX, largest power of two <= RING / NJ) slots of
@@ -740,15 +763,14 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
         auto issue = [&](int p, int slot) {
             if (OMNI_DBG(a, 2)) return;
             unsigned char* dst = e2b_smem + (unsigned)slot * slot_bytes;
-            const unsigned so = (unsigned)p * planeb;
+            const unsigned so = (unsigned)(p_start + p) * planeb;
 #pragma unroll
             for (int q = 0; q < NJ; ++q) e2b_dma16(rs, dst + q * 1024, g[q], so);
         };
         T* dst = out;
-        int cc = 0;
-        auto consume = [&](int slot) {
+        int cc = c0p;
+        auto consume = [&](int slot, float (&r)[NPX]) {
             const unsigned char* box = e2b_smem + (unsigned)slot * slot_bytes;
-            float r[NPX];
 #pragma unroll
             for (int k = 0; k < NPX; ++k) {
                 float a0, a1, b0, b1;
@@ -757,14 +779,18 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
                 r[k] = e2p_blend(a0, a1, b0, b1, w00[k], w01[k], w10[k], w11[k]);
             }
             if (ROWMAP) e2b_quad_transpose(r, lane);
-            if (!OMNI_DBG(a, 1)) E2BStore4<T>::st(dst, r);
+        };
+        auto store = [&](const float (&r)[NPX]) {
+            if (!OMNI_DBG(a, 1)) { if (a.store_mode) E2BStore4<T>::st_mode(dst, r, a.store_mode); else E2BStore4<T>::st(dst, r); }
             dst += plane;
             if (++cc == a.C) { cc = 0; dst += bskip; }
         };
-        // groups of NB stages, then planes % NB single stages (NB <= planes, host-checked).  vmcnt counts, per stage s of a group (in-order completion; the ONE
-        // store of a stage counts like a DMA piece):  first group  (NB-1) NJ + s   |  middle  (NB-1)(1 + NJ)
+        // groups of NB stages, then np % NB single stages (NB <= np: the work table never cuts a range shorter).  vmcnt counts, per stage s of a
+        // group (in-order completion; the ONE store of a stage counts like a DMA piece):  first group  (NB-1) NJ + s   |  middle  (NB-1)(1 + NJ)
         //                                             last group   (NB-1) + (NB-1-s) NJ   |  only group  (NB-1-s) NJ + s
-        const int groups = planes / NB;
+        // (round 3: issuing a stage's refill BEFORE its store, so that a write acknowledge has two stage-times instead of one before a
+        //  counted wait can stall on it, measured no different: 39.3 vs 38.5 us — the stores are not what the waits wait for)
+        const int groups = np / NB;
 #pragma unroll
         for (int d = 0; d < NB; ++d) issue(d, d);
         auto group = [&]<int KIND>(std::integral_constant<int, KIND>, int p0) {
@@ -773,7 +799,9 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
                     constexpr int CNT = KIND == 0 ? (NB - 1) * NJ + S : KIND == 1 ? (NB - 1) * (1 + NJ)
                                       : KIND == 2 ? (NB - 1) + (NB - 1 - S) * NJ : (NB - 1 - S) * NJ + S;
                     e2b_wait_vm<CNT>();
-                    consume(S);
+                    float r[NPX];
+                    consume(S, r);
+                    store(r);
                     if (KIND <= 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(p0 + S + NB, S); }
                 }()), ...);
             }(std::make_integer_sequence<int, NB>());
@@ -784,11 +812,13 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
             for (int gi = 1; gi + 1 < groups; ++gi) group(std::integral_constant<int, 1>(), gi * NB);
             group(std::integral_constant<int, 2>(), (groups - 1) * NB);
         }
-        for (int p = groups * NB; p < planes; ++p) {             // an odd plane count (3 planes of ONE panorama): the rest, one stage at a time
+        for (int p = groups * NB; p < np; ++p) {                 // an odd plane count (3 planes of ONE panorama): the rest, one stage at a time
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue(p, 0);
             e2b_wait_vm<0>();
-            consume(0);
+            float r[NPX];
+            consume(0, r);
+            store(r);
         }
     };
     switch (njj) {
@@ -800,6 +830,14 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint2* 
     case 6: run(std::integral_constant<int, 6>()); break;
     case 7: run(std::integral_constant<int, 7>()); break;
     default: run(std::integral_constant<int, 8>()); break;
+    }
+    if (OMNI_DBG(a, 16)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && a.trace) {
+            long long* t = a.trace + 4 * (size_t)blockIdx.x;
+            t[0] = tr0; t[1] = tr1; t[2] = wall_clock64();
+            t[3] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((long long)njj << 40);
+        }
     }
 }
 
@@ -936,9 +974,11 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
     a.sx_scale = (float)(g->W - 1) / 2.0f; a.sy_scale = (float)(g->H - 1) / 2.0f;
     a.tab = g->e2p;
     a.ixy = g->e2p_ixy;
-    a.dbg = 0;
+    a.dbg = 0; a.trace = nullptr;
+    a.store_mode = omni_options().e2p_store;
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_E2P_DBG");
+    a.trace = omni_debug_trace_buf();
 #endif
 }
 
@@ -1036,11 +1076,13 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
             std::vector<int> ord(mx * 8, -1);
             for (int x = 0; x < 8; ++x) for (size_t i = 0; i < sec[x].size(); ++i) ord[i * 8 + x] = sec[x][i].second;
             tt.norder = (int)ord.size();
+            tt.h_ent = he; tt.h_order = ord;
             if (tt.norder > 0) {
                 OMNI_HIP(hipMalloc((void**)&tt.order, sizeof(int) * ord.size()));
                 OMNI_HIP(hipMemcpy(tt.order, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
             }
         }
+        tt.h_fb.assign(hs.begin() + 2, hs.begin() + 2 + tt.nfb);
         if (tt.nfb > 0) {
             OMNI_HIP(hipMalloc((void**)&tt.fb, sizeof(int) * (size_t)tt.nfb));
             OMNI_HIP(hipMemcpy(tt.fb, hs.data() + 2, sizeof(int) * (size_t)tt.nfb, hipMemcpyHostToDevice));
@@ -1055,15 +1097,73 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
 }
 
 namespace {
-template <typename T, int NBMAX>
-int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, size_t tensor_bytes, hipStream_t stream)
+// ---- work table of e2p_box_kernel for one plane count: which (tile, plane range) each block processes.
+// A block's life is set-up (~2.6 us: table entry -> sampling coordinates -> taps) + np stages; with ONE block per tile, 4372 streaming blocks of
+// ~16 us each on the 3072 wave slots of the chip (12 per CU: the LDS ring) are 1.42 rounds — per-block time stamps (tools/trace_resample.py,
+// profiles/r03a_trace.txt) show the chip full only from 8 to 24 us of a 36-us launch: the gather blocks of the pole tiles took 60 % of the slots
+// for the first 5 us, and the second round ran at 40 % occupancy.  List scheduling, longest first: every XCD gets as many whole tiles as it has
+// slots, the remaining tiles are cut into `split` plane ranges (short blocks that fill the slots the long ones free, and end together), and the
+// gather blocks — the shortest — come last.  Block b runs on XCD b % 8: column x of the table holds tiles of ERP region x only.
+struct E2PWork { uint4* dev = nullptr; int nblocks = 0; };
+
+template <int E>
+int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWork& out)
 {
-    const auto& tt = g->e2p_boxes[sizeof(T) == 2 ? 1 : 0];
-    const int nfb_blocks = tt.nfb * B, lds_start = (nfb_blocks + 7) / 8 * 8;
+    omni_geometry* g = const_cast<omni_geometry*>(gc);             // (the cache is a mutable part of the handle)
+    auto& tt = g->e2p_boxes[E];
+    const OmniOptions& o = omni_options();
+    const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : 12, split = o.e2p_split > 0 ? o.e2p_split : 2, fbp = o.e2p_fb_planes > 0 ? o.e2p_fb_planes : C;
+    const long long key = ((long long)planes << 32) | ((long long)(C & 0xff) << 24) | ((long long)(slots_cu & 0xff) << 16) | ((long long)(split & 0xff) << 8) | (long long)((fbp & 0xf) << 4 | (nbmax & 0xf));
+    std::lock_guard<std::mutex> lk(g->work_mu);
+    for (auto& w : tt.work) if (w.key == key) { out.dev = w.dev; out.nblocks = w.nblocks; return OMNI_OK; }
+    const int slots_xcd = slots_cu * (omni_num_cus() / 8);
+    std::vector<std::vector<uint4>> col(8);
+    auto seg = [&](int wid, bool fb, int p0, int np) { return make_uint4((unsigned)wid | (fb ? 0x80000000u : 0u), (unsigned)p0 | ((unsigned)np << 16), tt.h_ent[wid].x, tt.h_ent[wid].y); };
+    // streaming tiles, in the region order of the geometry (order[k]: XCD k % 8)
+    std::vector<std::vector<int>> tiles(8);
+    for (int k = 0; k < tt.norder; ++k) if (tt.h_order[k] >= 0) tiles[k % 8].push_back(tt.h_order[k]);
+    const int parts = std::max(1, std::min(split, planes / std::max(1, nbmax)));
+    for (int x = 0; x < 8; ++x) {
+        const int nt = (int)tiles[x].size();
+        // whole tiles while they fill the slots exactly once; the rest in `parts` ranges (all of one range first: blocks that start together run the same planes)
+        const int nfull = nt <= slots_xcd ? nt : (o.e2p_full >= 0 ? std::min(nt, slots_xcd * o.e2p_full / 100) : slots_xcd);
+        for (int i = 0; i < nfull; ++i) col[x].push_back(seg(tiles[x][i], false, 0, planes));
+        for (int q = 0; q < parts; ++q) {
+            const int p0 = (int)((long long)planes * q / parts), p1 = (int)((long long)planes * (q + 1) / parts);
+            for (int i = nfull; i < nt; ++i) col[x].push_back(seg(tiles[x][i], false, p0, p1 - p0));
+        }
+    }
+    // gather tiles: ranges of fbp planes, spread over the XCDs, last
+    {
+        int x = 0;
+        for (int f = 0; f < tt.nfb; ++f)
+            for (int p0 = 0; p0 < planes; p0 += fbp) { col[x].push_back(seg(tt.h_fb[f], true, p0, std::min(fbp, planes - p0))); x = (x + 1) & 7; }
+    }
+    size_t mx = 0;
+    for (auto& c : col) mx = std::max(mx, c.size());
+    std::vector<uint4> tab(mx * 8, make_uint4(0u, 0u, 0u, 0u));
+    for (int x = 0; x < 8; ++x) for (size_t i = 0; i < col[x].size(); ++i) tab[i * 8 + x] = col[x][i];
+    if (tab.empty()) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: empty work table");
+    uint4* dev = nullptr;
+    OMNI_HIP(hipMalloc((void**)&dev, sizeof(uint4) * tab.size()));
+    if (hipMemcpy(dev, tab.data(), sizeof(uint4) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); OMNI_FAIL(OMNI_ERR_HIP, "omni_equi2pers: work table upload"); }
+    if (tt.work.size() >= 16) { (void)hipDeviceSynchronize(); (void)hipFree(tt.work.front().dev); tt.work.erase(tt.work.begin()); }   // (tuning sweeps only: 16 plane counts x option sets)
+    tt.work.push_back({key, dev, (int)tab.size()});
+    out.dev = dev; out.nblocks = (int)tab.size();
+    return OMNI_OK;
+}
+
+template <typename T, int NBMAX>
+int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t tensor_bytes, hipStream_t stream)
+{
+    constexpr int E = sizeof(T) == 2 ? 1 : 0;
+    const auto& tt = g->e2p_boxes[E];
+    E2PWork wk;
+    int rc = e2p_work_table<E>(g, B * C, C, NBMAX, wk);
+    if (rc != OMNI_OK) return rc;
     const int njmax = (tt.max_chunks + 63) / 64;
     const size_t lds = (size_t)(njmax > E2B_RING_KB ? njmax : E2B_RING_KB) * 1024;
-    hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2>), dim3(lds_start + tt.norder), dim3(64), lds, stream, a,
-                       (const uint2*)tt.ent, tt.tx, tt.tx * tt.ty, (const int*)tt.fb, nfb_blocks, (const int*)tt.order, lds_start,
+    hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2>), dim3(wk.nblocks), dim3(64), lds, stream, a, (const uint4*)wk.dev, tt.tx, tt.tx * tt.ty,
                        (unsigned)tensor_bytes);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
@@ -1074,11 +1174,12 @@ int launch_e2b(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t te
 {
     // stages in flight: 1, 2 or 4 (option e2p_nbuf), at most the plane count (the stage loop runs in groups of NB, the remainder singly)
     const int planes = B * C;
+    if (planes >= 65536) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: B * C must be < 65536");
     int nb = omni_options().e2p_nbuf;
     if (nb <= 0) nb = 2;                               // (4 stages in flight measured slower: 41.5 vs 38.3 us at B = 8, 18 x 256^2)
-    if (nb >= 4 && planes >= 4) return launch_e2b_nb<T, 4>(a, g, B, tensor_bytes, stream);
-    if (nb >= 2 && planes >= 2) return launch_e2b_nb<T, 2>(a, g, B, tensor_bytes, stream);
-    return launch_e2b_nb<T, 1>(a, g, B, tensor_bytes, stream);
+    if (nb >= 4 && planes >= 4) return launch_e2b_nb<T, 4>(a, g, B, C, tensor_bytes, stream);
+    if (nb >= 2 && planes >= 2) return launch_e2b_nb<T, 2>(a, g, B, C, tensor_bytes, stream);
+    return launch_e2b_nb<T, 1>(a, g, B, C, tensor_bytes, stream);
 }
 
 template <typename T>

@@ -37,6 +37,11 @@ const OptName kOpts[] = {
     {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
     {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},
     {"e2p_slot_kb", "OMNI_E2P_SLOT_KB", &OmniOptions::e2p_slot_kb, 6},
+    {"e2p_store", "OMNI_E2P_STORE", &OmniOptions::e2p_store, 1},
+    {"e2p_slots", "OMNI_E2P_SLOTS", &OmniOptions::e2p_slots, 0},
+    {"e2p_split", "OMNI_E2P_SPLIT", &OmniOptions::e2p_split, 0},
+    {"e2p_full", "OMNI_E2P_FULL", &OmniOptions::e2p_full, -1},
+    {"e2p_fb_planes", "OMNI_E2P_FB_PLANES", &OmniOptions::e2p_fb_planes, 0},
     {"p2e_nbuf", "OMNI_P2E_NBUF", &OmniOptions::p2e_nbuf, 0},
     {"p2e_planes", "OMNI_P2E_PLANES", &OmniOptions::p2e_planes, 0},
     {"geom_cache_max", "OMNI_GEOM_CACHE_MAX", &OmniOptions::geom_cache_max, 16},
@@ -86,6 +91,10 @@ extern "C" int omni_get_option(const char* name, int* value)
 
 #ifdef OMNI_DEBUG_BUILD
 int omni_debug_bits(const char* env_name) { const char* d = getenv(env_name); return d ? atoi(d) : 0; }
+static long long* g_omni_trace = nullptr;
+long long* omni_debug_trace_buf() { return g_omni_trace; }
+// tools/: per-block time stamps of the resample kernels (bit 16 of OMNI_E2P_DBG / OMNI_P2E_DBG), 4 x int64 per block
+extern "C" int omni_debug_set_trace(long long* buf) { g_omni_trace = buf; return OMNI_OK; }
 #endif
 
 // ---------------------------------------------------------------- presets
@@ -183,7 +192,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     centers(nrows, 0, nullptr, nullptr, g->center_p);
     g->row_trig = nullptr; g->col_trig = nullptr; g->cand = nullptr; g->ntx = (W + 63) / 64;
     g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0; g->e2p_ixy = nullptr; g->e2p_ts = 32;
-    for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; }
+    for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.ord = nullptr; t.nslots = 0; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; t.sum_chunks = 0; }
     for (auto& t : g->e2p_boxes) { t.ent = nullptr; t.fb = nullptr; t.order = nullptr; t.norder = 0; t.nfb = 0; t.max_chunks = 0; t.ok = 0; t.tw = t.th = t.tx = t.ty = 0; }
     g->p2e_tx = g->p2e_ty = 0;
     g->p2e_bwd_box = nullptr; g->p2e_rden = nullptr; g->p2e_btx = g->p2e_bty = g->p2e_bwd_ok = 0;
@@ -217,11 +226,11 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->row_trig) (void)hipFree(g->row_trig);
     if (g->col_trig) (void)hipFree(g->col_trig);
     if (g->cand) (void)hipFree(g->cand);
-    for (auto& t : g->p2e_tiles) if (t.ent) (void)hipFree(t.ent);
+    for (auto& t : g->p2e_tiles) { if (t.ent) (void)hipFree(t.ent); if (t.ord) (void)hipFree(t.ord); }
     if (g->p2e_bwd_box) (void)hipFree(g->p2e_bwd_box);
     if (g->p2e_rden) (void)hipFree(g->p2e_rden);
     if (g->p2e_bwd_ids) (void)hipFree(g->p2e_bwd_ids);
-    for (auto& t : g->e2p_boxes) { if (t.ent) (void)hipFree(t.ent); if (t.fb) (void)hipFree(t.fb); if (t.order) (void)hipFree(t.order); }
+    for (auto& t : g->e2p_boxes) { if (t.ent) (void)hipFree(t.ent); if (t.fb) (void)hipFree(t.fb); if (t.order) (void)hipFree(t.order); for (auto& w : t.work) (void)hipFree(w.dev); }
     if (g->e2p_fb_tiles) (void)hipFree(g->e2p_fb_tiles);
     if (g->e2p_ixy) (void)hipFree(g->e2p_ixy);
     if (g->e2p_bwd_box) (void)hipFree(g->e2p_bwd_box);

@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/omnifusion.h"
 
@@ -35,6 +36,11 @@ struct OmniOptions {
     int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 1: pers2equi backward by global atomics (the round-1 kernel) instead of patch-tile gathers
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
+    int e2p_store;        // OMNI_E2P_STORE      cache policy of the patch stores of the equi2pers box kernel: 0 plain | 1 nt (default: 106 -> 74 us at 16 panoramas, where the 327 MB of a launch exceed the 256-MB memory-side cache) | 2 sc1 | 3 sc0 sc1
+    int e2p_slots;        // OMNI_E2P_SLOTS      wave slots per CU the equi2pers work table plans for (0: 12, what the 12-KiB ring admits)
+    int e2p_split;        // OMNI_E2P_SPLIT      plane ranges a tile beyond the first round of slots is cut into (0: 2)
+    int e2p_full;         // OMNI_E2P_FULL       -1: one whole tile per slot first; else that percentage of the slots
+    int e2p_fb_planes;    // OMNI_E2P_FB_PLANES  planes per gather block of a pole tile (0: C)
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
@@ -48,6 +54,7 @@ int omni_num_cus();                // compute units of the current device (cache
 #ifdef OMNI_DEBUG_BUILD
 #define OMNI_DBG(a, bit) (((a).dbg & (bit)) != 0)
 int omni_debug_bits(const char* env_name);
+long long* omni_debug_trace_buf();   // device buffer set by omni_debug_set_trace (4 x int64 per block: start, set-up done, end, HW_ID | XCC_ID << 32), or null
 #else
 #define OMNI_DBG(a, bit) false
 #endif
@@ -80,7 +87,7 @@ struct omni_geometry {
     int ntx;
     // pers2equi LDS path: per ERP tile (P2E_TH x P2E_TW pixels) the list of covering patches with the bounding box of their
     // bilinear taps inside the patch (omni_pers2equi.hip); index 0: 4-byte elements, 1: 2-byte elements (16-byte chunk alignment)
-    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; } p2e_tiles[2];
+    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; int sum_chunks; uint2* ord; int nslots; } p2e_tiles[2];   // ord: the table in block order (+ tile id), what the kernels read
     int p2e_tx, p2e_ty;            // tiles per ERP row / column
     // pers2equi backward by gathers (omni_pers2equi.hip): per (patch, 4 x 32 patch tile) the ERP box of the pixels whose taps touch it
     // (columns relative to the patch's centre column: the box may cross the +-pi seam), and 1 / (L1 norm of the tap weights) per ERP pixel
@@ -88,8 +95,12 @@ struct omni_geometry {
     int* p2e_bwd_ids; int p2e_bwd_nsmall, p2e_bwd_nbig;   // tile ids: [0, nsmall) boxes of <= 2048 pixels (one wave each), then the big ones (1024 threads each)
     // equi2pers LDS path (omni_equi2pers.hip, e2p_box_kernel): per (patch, sample tile) the bounding box of the bilinear taps on
     // the ERP; index 0: 4-byte elements (8 x 32 sample tiles), 1: 2-byte elements (4 x 64); fb = tiles whose box exceeds the slot
+    struct E2PWorkTab { long long key; uint4* dev; int nblocks; };
     struct E2PTiles { uint2* ent; int* fb; int nfb; int max_chunks; int tw, th, tx, ty; int ok;
-                      int* order; int norder; } e2p_boxes[2];   // order: LDS-path tiles grouped by ERP longitude sector, one sector per XCD (-1 = padding)
+                      int* order; int norder;                 // order: LDS-path tiles grouped by ERP longitude sector, one sector per XCD (-1 = padding)
+                      std::vector<uint2> h_ent; std::vector<int> h_order, h_fb;   // host copies: the work tables are built from them
+                      std::vector<E2PWorkTab> work; } e2p_boxes[2];               // work tables of e2p_box_kernel, one per plane count (omni_equi2pers.hip)
+    std::mutex work_mu;
     int* e2p_fb_tiles;             // equi2pers backward: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box
     int e2p_nfb;
     int e2p_ts;                    // equi2pers: tile side (32 or 16 samples) chosen so that the footprints fit the LDS box

@@ -25,6 +25,8 @@
 // HBM-bound: algorithmic bytes B*C*(ph*pw*N + H*W)*sizeof(T); tables read: 8 B per tile.
 #include <stdio.h>
 #include <utility>
+#include <vector>
+#include <algorithm>
 #include "omni_internal.h"
 
 namespace {
@@ -39,6 +41,7 @@ struct P2EArgs {
     float kx, ky;                              // 1/(FOVx*PI), 1/(FOVy*PI_2)   (:115-116)
     float half_h, half_w;                      // 0.5*height, 0.5*width        (:122-123)
     int dbg;                                   // debug build only (OMNI_P2E_DBG ablation bits): 1 no tap geometry, 2 no LDS tap reads, 4 no DMA, 8 no stores
+    long long* trace;                          // debug build, bit 16: per-block time stamps (omni_debug_set_trace)
     PatchTab tab;
 };
 
@@ -54,9 +57,8 @@ __device__ __forceinline__ void p2e_lon(const P2EArgs& a, int n, float slon, flo
     cd = clon * cl0 + slon * sl0;                                   // cos(lon - l0)
     sd = slon * cl0 - clon * sl0;                                   // sin(lon - l0)
 }
-__device__ __forceinline__ bool p2e_taps_cs(const P2EArgs& a, int n, float slat, float clat, float cd, float sd, Taps& t)
+__device__ __forceinline__ bool p2e_taps_core(const P2EArgs& a, float sp, float cp, float slat, float clat, float cd, float sd, Taps& t)
 {
-    const float sp = a.tab.sphi[n], cp = a.tab.cphi[n];
     const float cos_c = sp * slat + cp * clat * cd;                 // :112
     // :113-114 divide twice by cos_c; one reciprocal and two products differ from that by <= 2 ulp of X, Y (a
     // validity / floor predicate can flip only where the reference's own coordinate is within round-off of the step)
@@ -94,6 +96,10 @@ __device__ __forceinline__ bool p2e_taps_cs(const P2EArgs& a, int n, float slat,
     t.wa = xedge ? 0.0f : t.wa;
     t.x0 = (int)x0f; t.x1 = (int)x1f; t.y0 = (int)y0f; t.y1 = (int)y1f;
     return valid;
+}
+__device__ __forceinline__ bool p2e_taps_cs(const P2EArgs& a, int n, float slat, float clat, float cd, float sd, Taps& t)
+{
+    return p2e_taps_core(a, a.tab.sphi[n], a.tab.cphi[n], slat, clat, cd, sd, t);
 }
 __device__ __forceinline__ bool p2e_taps(const P2EArgs& a, int n, float slat, float clat, float slon, float clon, Taps& t)
 {
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
 constexpr int P2E_TH = 4, P2E_TW = 32;          // ERP tile of one wave: NPX = TH/2 pixels per lane (lane -> column lane%32, rows lane/32 + 2k)
 constexpr int P2E_NPX = P2E_TH / 2;
 constexpr int P2E_MAXC = 12;                    // table entries (covering patches) per tile
+constexpr int P2E_ENT = P2E_MAXC + 1;           // uint2 per block slot of the ORDERED table the kernels read: the entries, then {tile id | -1, 0}
 constexpr int P2E_NJMAX = 8;                    // 1-KiB DMA pieces per box at most: boxes up to 8 KiB
 constexpr int P2E_MAX_CHUNKS = 64 * P2E_NJMAX;
 
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __rest
     const int j = tj * P2E_TW + col;
     const bool jin = j < a.W;
     const float2 ct = a.col_trig[jin ? j : a.W - 1];
-    int cnt = 0, maxch = 0;
+    int cnt = 0, maxch = 0, sumch = 0;
     for (int n = 0; n < a.tab.N; ++n) {
         int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
 #pragma unroll
@@ -309,6 +316,7 @@ __global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __rest
         const int bh = ymax - ymin + 1;
         const bool fits = bw4 < 1024 && bh < 1024 && xa < 65536 && ymin < 65536 && bw4 * bh <= P2E_MAX_CHUNKS;
         maxch = max(maxch, fits ? bw4 * bh : P2E_MAX_CHUNKS + 1);
+        sumch += fits ? bw4 * bh : (1 << 20);
         if (lane == 0 && cnt < P2E_MAXC && fits)
             ent[(size_t)wid * P2E_MAXC + cnt] = make_uint2((unsigned)n | ((unsigned)bw4 << 6) | ((unsigned)bh << 16),
                                                            (unsigned)xa | ((unsigned)ymin << 16));
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __rest
     if (lane == 0) {
         for (int c = cnt; c < P2E_MAXC; ++c) ent[(size_t)wid * P2E_MAXC + c] = make_uint2(0u, 0u);
         if (cnt <= P2E_MAXC) ent[(size_t)wid * P2E_MAXC].x |= (unsigned)cnt << 26;
-        atomicMax(&stats[0], maxch); atomicMax(&stats[1], cnt);
+        atomicMax(&stats[0], maxch); atomicMax(&stats[1], cnt); atomicMax(&stats[2], sumch);
     }
 }
 
@@ -389,9 +397,14 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     extern __shared__ __attribute__((aligned(16))) unsigned char p2e_smem[];        // the ONLY LDS object of this kernel
     constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = P2E_NPX;
     const int lane = threadIdx.x;
-    int ti, tj;
-    if (!omni_xcd_rows(blockIdx.x, tiles_y, tiles_x, ti, tj)) return;               // (block-uniform)
-    const int wid = ti * tiles_x + tj;
+    long long tr0 = 0, tr1 = 0;
+    if (OMNI_DBG(a, 16)) tr0 = wall_clock64();
+    // block -> tile: the ordered table of the geometry (omni_p2e_build_tiles: whole bands of tile rows per XCD, and inside an XCD the
+    // tiles dealt so that every CU gets the same amount of work; slot blockIdx.x holds the tile's entries and its id)
+    const uint2* __restrict__ te = tiles + (size_t)blockIdx.x * P2E_ENT;
+    const int wid = (int)te[P2E_MAXC].x;
+    if (wid < 0) return;                                                            // padding slot (block-uniform)
+    const int ti = wid / tiles_x, tj = wid - ti * tiles_x;
     const int col = lane & 31, rsub = lane >> 5;
     const int j = tj * P2E_TW + col;
     const bool jin = j < a.W;
@@ -406,7 +419,6 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     float2 rt[NPX];
 #pragma unroll
     for (int k = 0; k < NPX; ++k) rt[k] = a.row_trig[min(ti * P2E_TH + rsub + 2 * k, a.H - 1)];
-    const uint2* __restrict__ te = tiles + (size_t)wid * P2E_MAXC;
     const int ncand = (int)(te[0].x >> 26);
     unsigned poff_l;                                               // lane p: byte offset of plane p_begin + p (< 2^31, host-checked)
     {
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
 #pragma unroll
     for (int k = 0; k < NPX; ++k) asm volatile("" ::"v"(rt[k].x), "v"(rt[k].y));
 
+    if (OMNI_DBG(a, 16)) tr1 = wall_clock64();
     float acc[PL][NPX], acc2[CONF ? PL : 1][NPX], l1[NPX];
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
@@ -560,8 +573,25 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
             }
         }
     }
+    if (OMNI_DBG(a, 16)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && a.trace) {
+            long long* t = a.trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            t[0] = tr0; t[1] = tr1; t[2] = wall_clock64();
+            t[3] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((long long)ncand << 40);
+        }
+    }
 }
 
+// ------------------------------------------------------------------ (round 3: a plane-major form of this kernel, measured and dropped)
+// p2e_tile_kernel swapped the loops: set-up once per tile (all table entries and patch constants in one batch of scalar loads, the taps of
+// EVERY covering patch in registers, 6 per pixel and patch), then ONE pipeline of PL stages per tile, a stage = the boxes of all covering
+// patches of one plane packed back to back into one ring slot (13.3 instead of 16.5 MB of LDS-DMA per plane at cfg 1), the blend of a pixel
+// a loop over patches inside the stage.  Same bits.  B = 8, 18 x 256^2: 19.3 us against 18.4 us for the patch-by-patch kernel above (17.2 vs
+// 15.9 with the balanced block order), 46.9 vs 33.3 us at nrows = 6: its per-block phases (tools/trace_resample.py) were loads 1.3 us, DMA
+// addresses + ring fill 1.4, taps 1.4, the 8 stages 4.8, stores 0.8 for a 2-patch tile and still grew by 2.5 us per patch — a block's time is
+// the WORK per patch (bytes, taps, geometry) divided by a throughput 16 waves per CU share, not the number of dependent pipelines.
+// What the same traces did show: the CU on a patch seam had 56 patch-tiles to the median CU's 34 — see the block order in omni_p2e_build_tiles.
 // ------------------------------------------------------------------ backward
 // g_pers[b,c,y,x,n] = sum over the ERP pixels (i,j) whose tap of patch n is (y,x) of w~ * g_erp[b,c,i,j], w~ the thresholded,
 // L1-normalised weights of the forward (the operator is linear in the patches; the weights do not depend on them).
@@ -628,9 +658,10 @@ int fill_args(P2EArgs& a, const omni_geometry* g, const void* pers, const void* 
     a.ky = (float)(1.0 / ((double)(g->fov_h / 180.0f) * (double)PI2f));
     a.half_h = 0.5f * (float)g->ph; a.half_w = 0.5f * (float)g->pw;
     a.tab = g->p2e;
-    a.dbg = 0;
+    a.dbg = 0; a.trace = nullptr;
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_P2E_DBG");
+    a.trace = omni_debug_trace_buf();
 #endif
     return OMNI_OK;
 }
@@ -652,8 +683,8 @@ int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int p_first, int
     const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
     const int stage_kb = (tt.max_chunks + 63) / 64 * (CONF ? 2 : 1);
     const size_t lds = (size_t)(stage_kb > P2E_RING_KB ? stage_kb : P2E_RING_KB) * 1024;
-    hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NBMAX>), dim3(omni_xcd_rows_grid(g->p2e_ty, g->p2e_tx), planes / PL), dim3(64), lds, stream, a,
-                       (const uint2*)tt.ent, g->p2e_tx, g->p2e_ty, (unsigned)tensor_bytes, p_first);
+    hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NBMAX>), dim3(tt.nslots, planes / PL), dim3(64), lds, stream, a,
+                       (const uint2*)tt.ord, g->p2e_tx, g->p2e_ty, (unsigned)tensor_bytes, p_first);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
@@ -746,21 +777,66 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
     const long long ntiles = (long long)g->p2e_tx * g->p2e_ty;
     if (ntiles >= (1ll << 28)) return OMNI_OK;                     // absurd sizes: gather path only
     int* dstats = nullptr;
-    OMNI_HIP(hipMalloc((void**)&dstats, 2 * sizeof(int)));
+    OMNI_HIP(hipMalloc((void**)&dstats, 3 * sizeof(int)));
     for (int e = 0; e < 2; ++e) {
         auto& tt = g->p2e_tiles[e];
         const int epc = e ? 8 : 4;
         if (hipMalloc((void**)&tt.ent, sizeof(uint2) * (size_t)ntiles * P2E_MAXC) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: out of memory"); }
-        if (hipMemsetAsync(dstats, 0, 2 * sizeof(int), stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: memset"); }
+        if (hipMemsetAsync(dstats, 0, 3 * sizeof(int), stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: memset"); }
         hipLaunchKernelGGL(p2e_tiles_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, a, tt.ent, g->p2e_tx, (int)ntiles, epc, dstats);
-        int hs[2] = {0, 0};
+        int hs[3] = {0, 0, 0};
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, dstats, sizeof(hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: kernel failed"); }
         tt.max_chunks = hs[0]; tt.max_cand = hs[1];
         tt.ok = (hs[0] <= P2E_MAX_CHUNKS && hs[1] <= P2E_MAXC && g->pw % epc == 0) ? 1 : 0;
+        tt.sum_chunks = hs[2];
+        if (tt.ok) {
+            // ---- block order.  A block's duration grows with the number of covering patches of its tile (3.3 us + 2.9 us per patch at
+            // cfg 1, tools/trace_resample.py), all blocks of a BASELINE-size launch are resident at once, and the dispatcher deals an XCD's
+            // blocks to its 32 CUs round-robin (block b -> XCD b % 8, CU (b / 8) % 32 of it: tools/trace_cu.py) — with 32 tiles per ERP
+            // row every CU got ONE column strip of the image and the CU on a patch seam 56 patch-tiles where the median CU has 34; the
+            // launch ended when that CU did (17.4 us for blocks of 9.8 us on average).  So: whole bands of tile rows per XCD as before
+            // (vertical neighbours share their boxes in one L2), bands dealt to the XCDs by cost (heaviest with lightest), and inside an
+            // XCD the tiles sorted by cost and dealt to the 32 round-robin positions in snake order.  Pure speed: any order is correct.
+            std::vector<uint2> he((size_t)ntiles * P2E_MAXC);
+            if (hipMemcpy(he.data(), tt.ent, sizeof(uint2) * he.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: copy"); }
+            const int tx = g->p2e_tx, ty = g->p2e_ty, band = omni_xcd_band_rows(ty), nbands = (ty + band - 1) / band;
+            auto cost = [&](int wid) { return 2 + (int)(he[(size_t)wid * P2E_MAXC].x >> 26); };
+            std::vector<std::pair<long long, int>> bc(nbands);
+            for (int b = 0; b < nbands; ++b) {
+                long long c = 0;
+                for (int r = b * band; r < std::min(ty, (b + 1) * band); ++r) for (int x = 0; x < tx; ++x) c += cost(r * tx + x);
+                bc[b] = {-c, b};
+            }
+            std::sort(bc.begin(), bc.end());
+            std::vector<std::vector<int>> per(8);
+            for (int k = 0; k < nbands; ++k) {
+                const int r = k / 8, i = k % 8, xcd = (r & 1) ? 7 - i : i, b = bc[k].second;
+                for (int row = b * band; row < std::min(ty, (b + 1) * band); ++row) for (int x = 0; x < tx; ++x) per[xcd].push_back(row * tx + x);
+            }
+            size_t mx = 0;
+            for (auto& v : per) {
+                std::stable_sort(v.begin(), v.end(), [&](int p, int q) { return cost(p) > cost(q); });
+                mx = std::max(mx, v.size());
+            }
+            const size_t rounds = (mx + 31) / 32;
+            tt.nslots = (int)(rounds * 32 * 8);
+            std::vector<uint2> ord((size_t)tt.nslots * P2E_ENT, make_uint2(0u, 0u));
+            for (int s2 = 0; s2 < tt.nslots; ++s2) ord[(size_t)s2 * P2E_ENT + P2E_MAXC].x = 0xffffffffu;
+            for (int xcd = 0; xcd < 8; ++xcd)
+                for (size_t k = 0; k < per[xcd].size(); ++k) {
+                    const size_t r = k / 32, i = k % 32, pos = r * 32 + ((r & 1) ? 31 - i : i);
+                    const size_t slot = pos * 8 + (size_t)xcd;
+                    const int wid = per[xcd][k];
+                    for (int c = 0; c < P2E_MAXC; ++c) ord[slot * P2E_ENT + c] = he[(size_t)wid * P2E_MAXC + c];
+                    ord[slot * P2E_ENT + P2E_MAXC] = make_uint2((unsigned)wid, 0u);
+                }
+            if (hipMalloc((void**)&tt.ord, sizeof(uint2) * ord.size()) != hipSuccess ||
+                hipMemcpy(tt.ord, ord.data(), sizeof(uint2) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: order table"); }
+        }
         if (omni_options().e2p_verbose)
-            fprintf(stderr, "[omni] pers2equi %dx%d <- %d patches %dx%d, %d-byte elements: largest tap box %d chunks, <= %d patches per %dx%d tile -> %s\n",
-                    g->H, g->W, g->N, g->ph, g->pw, 16 / epc, hs[0], hs[1], P2E_TH, P2E_TW, tt.ok ? "LDS path" : "gather path");
+            fprintf(stderr, "[omni] pers2equi %dx%d <- %d patches %dx%d, %d-byte elements: largest tap box %d chunks, <= %d patches and <= %d chunks per %dx%d tile -> %s\n",
+                    g->H, g->W, g->N, g->ph, g->pw, 16 / epc, hs[0], hs[1], hs[2], P2E_TH, P2E_TW, tt.ok ? "LDS path" : "gather path");
     }
     (void)hipFree(dstats);
     return OMNI_OK;

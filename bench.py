@@ -76,6 +76,47 @@ def cpu_baseline():
                       f"({threads} threads) + C/OpenMP equi2pers/pers2equi"}
 
 
+def kernel_us(fns, dev, reps=20):
+    """Average launch duration (s) of each callable's kernel, HIP events on the launch stream: ONE event pair around `reps` back-to-back
+    launches of the same kernel, queued behind a few milliseconds of device-side spinning so that the host is never the one being timed.
+    This is the form that agrees with the dispatch time stamps of `rocprofv3 --kernel-trace --stats` (tools/evmethod.py, profiles/
+    r03b_event_method.txt: 36.1 / 15.9 us against 36.6 / 16.0 us; an event pair around EVERY launch reads 41.2 / 20.4 us — each
+    bracket adds ~4.5 us of command-processor time to a 16-us kernel)."""
+    out = []
+    for f in fns:
+        for _ in range(3): f()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(int(12e6))                          # ~5 ms of device time: the queue fills while it spins
+            e0.record()
+            for _ in range(reps): f()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1) / reps * 1e-3)
+        out.append(float(np.mean(ts)))
+    return out
+
+
+def resample_pair(dev, B, H, W, nrows, P, dtype, reps=20):
+    """The resample pair (equi2pers C = 3, pers2equi C = 1, planar layout) at one BASELINE shape: seconds per kernel + algorithmic bytes."""
+    from omnifusion_amd import _lib
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
+    from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi
+    N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+    s = 2 if dtype == torch.float16 else 4
+    x = torch.rand((B, 3, H, W), device=dev).to(dtype)
+    d = torch.rand((B, N, 1, P, P), device=dev).to(dtype)
+    LAY = _lib.LAYOUT_BNCHW
+    t1, t2 = kernel_us([lambda: equi2pers_patches(x, FOV, nrows, (P, P), layout=LAY),
+                        lambda: pers2equi(d, FOV, nrows, (P, P), (H, W), None, layout=LAY)], dev, reps)
+    b1, b2 = B * 3 * (H * W + P * P * N) * s, B * (P * P * N + H * W) * s
+    del x, d
+    return {"equi2pers_us": t1 * 1e6, "pers2equi_us": t2 * 1e6, "bytes": b1 + b2, "GB/s": (b1 + b2) / (t1 + t2) / 1e9,
+            "resample_pair_frac": (b1 + b2) / (t1 + t2) / 1e9 / HBM_PEAK_GBS}
+
+
 def pmc_traffic(B):
     """HBM bytes of the resample pair (one launch each) from profiles/resample_traffic.json, or (None, why)."""
     path = os.path.join(ROOT, "profiles", "resample_traffic.json")
@@ -124,6 +165,46 @@ def main():
     net.load_state_dict(make_state_dict(42, NPATCH, False))                   # random-init weights of the reference architecture
     eng = net._eng
     LAY = _lib.LAYOUT_BNCHW
+
+    # ---- the resample pair at the metric's patch size (18 x 256^2), same run, HIP events on the launch stream — measured BEFORE the
+    # matrix-bound steps, in its own steady state (after 2500 panoramas/s of MFMA load the chip sits at its power-capped clock and the
+    # same two kernels measure 5 % slower: round 2, 45.2 % in here vs 48 % in tools/kbench.py)
+    P = 256
+    depth_patches = torch.rand((B, NPATCH, 1, P, P), generator=g).to(dev)
+    K = max(args.steps, 20)
+    f_e2p = lambda: equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY)
+    f_p2e = lambda: pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
+    t_heat = time.perf_counter()
+    while time.perf_counter() - t_heat < 0.2:
+        f_e2p(); f_p2e()
+        torch.cuda.synchronize()
+    r_e2p, r_p2e = kernel_us([f_e2p, f_p2e], dev, K)
+    # ... and as consecutive pipelined forwards run them: equi2pers of one batch beside pers2equi of another (two streams that really
+    # run side by side, host wall clock over K pairs)
+    from omnifusion_amd.model.spherical_model import _concurrent_streams
+    sa, sb = _concurrent_streams(2, dev)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t_pair = time.perf_counter()
+        for k in range(4 * K):
+            with torch.cuda.stream(sa):
+                f_e2p()
+            with torch.cuda.stream(sb):
+                f_p2e()
+        torch.cuda.synchronize()
+        t_pair = (time.perf_counter() - t_pair) / (4 * K)
+    bytes_e2p = B * 3 * (ERP_H * ERP_W + P * P * NPATCH) * 4          # SURVEY 8d algorithmic bytes
+    bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * 4
+    gbs_pair = (bytes_e2p + bytes_p2e) / (r_e2p + r_p2e) / 1e9
+    # ... and at the other BASELINE shapes (rank 0 only: they are kernel figures, not whole-job ones)
+    configs = {}
+    if rank == 0:
+        configs["b16"] = resample_pair(dev, 16, ERP_H, ERP_W, NROWS, 256, torch.float32)
+        configs["cfg3"] = resample_pair(dev, 1, 1024, 2048, 6, 256, torch.float32)
+        configs["cfg5"] = {"fp16": resample_pair(dev, 1, 2048, 4096, 6, 512, torch.float16),
+                           "fp32": resample_pair(dev, 1, 2048, 4096, 6, 512, torch.float32),
+                           "fp16_b4": resample_pair(dev, 4, 2048, 4096, 6, 512, torch.float16, reps=8)}
+        torch.cuda.empty_cache()
 
     # Bring the GPU out of its idle power state before anything is counted (sclk idles at ~366 MHz and takes tens of
     # milliseconds of load to ramp: a 5-step warm-up measured 1600-2200 panoramas/s on a box that then holds 2650).
@@ -182,41 +263,6 @@ def main():
     f16x3 = eng.precision == "f16x3"
     peak = MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS
 
-    # ---- the resample pair at the metric's patch size (18 x 256^2), same run, HIP events on the launch stream
-    P = 256
-    depth_patches = torch.rand((B, NPATCH, 1, P, P), generator=g).to(dev)
-    K = max(args.steps, 20)
-    for _ in range(3):
-        equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY); pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
-    er = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
-    torch.cuda.synchronize()
-    for k in range(K):
-        er[k][0].record()
-        equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY)
-        er[k][1].record()
-        pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
-        er[k][2].record()
-    torch.cuda.synchronize()
-    r_e2p = float(np.mean([er[k][0].elapsed_time(er[k][1]) for k in range(K)])) * 1e-3
-    r_p2e = float(np.mean([er[k][1].elapsed_time(er[k][2]) for k in range(K)])) * 1e-3
-    # ... and as consecutive pipelined forwards run them: equi2pers of one batch beside pers2equi of another (two streams that really
-    # run side by side, host wall clock over K pairs)
-    from omnifusion_amd.model.spherical_model import _concurrent_streams
-    sa, sb = _concurrent_streams(2, dev)
-    for rep in range(2):
-        torch.cuda.synchronize()
-        t_pair = time.perf_counter()
-        for k in range(4 * K):
-            with torch.cuda.stream(sa):
-                equi2pers_patches(rgb, FOV, NROWS, (P, P), layout=LAY)
-            with torch.cuda.stream(sb):
-                pers2equi(depth_patches, FOV, NROWS, (P, P), (ERP_H, ERP_W), None, layout=LAY)
-        torch.cuda.synchronize()
-        t_pair = (time.perf_counter() - t_pair) / (4 * K)
-    bytes_e2p = B * 3 * (ERP_H * ERP_W + P * P * NPATCH) * 4          # SURVEY 8d algorithmic bytes
-    bytes_p2e = B * 1 * (P * P * NPATCH + ERP_H * ERP_W) * 4
-    gbs_pair = (bytes_e2p + bytes_p2e) / (r_e2p + r_p2e) / 1e9
-
     traffic, traffic_note = pmc_traffic(B)
 
     # ---- the same step fed from HOST memory: decoded uint8 frames in pinned memory -> async H2D + /255 + CHW on a
@@ -224,12 +270,13 @@ def main():
     # never as `value` (the PCIe-inclusive rate).
     from omnifusion_amd.data import DeviceFeeder
     host_frames = [torch.randint(0, 256, (B, ERP_H, ERP_W, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(4)]
-    nfeed = max(20, args.steps)
+    nfeed = max(200, 2 * args.steps)                                  # (20 batches in round 2: the first ones pay the start-up, 64 % measured)
+    nskip = 4 * max(depth, 2)                                          # steady state: the clock starts when this many batches have been retired
     for _ in DeviceFeeder((host_frames[k % 4] for k in range(4)), (ERP_H, ERP_W), device=dev):
         pass
     torch.cuda.synchronize()
-    tf = time.perf_counter()
-    feeder = DeviceFeeder((host_frames[k % 4] for k in range(nfeed)), (ERP_H, ERP_W), device=dev, out_buffers=2 if depth > 1 else 1)
+    feeder = DeviceFeeder((host_frames[k % 4] for k in range(nfeed + nskip)), (ERP_H, ERP_W), device=dev, out_buffers=2 if depth > 1 else 1)
+    tf, nret = None, 0
     for frame_rgb in feeder:
         p_ = run(frame_rgb, confidence=True)
         if depth > 1:
@@ -237,10 +284,22 @@ def main():
         pending.append(p_)
         if len(pending) > depth:
             pending.popleft().get()
+            nret += 1
+            if nret == nskip:
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
     while pending:
         pending.popleft().get()
     torch.cuda.synchronize()
     host_fed = B * nfeed / (time.perf_counter() - tf)
+    # the link itself: one pinned 12.6-MB batch of frames, host -> device, back to back
+    hbuf = torch.empty_like(host_frames[0], device=dev)
+    for _ in range(3): hbuf.copy_(host_frames[0], non_blocking=True)
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    for k in range(50): hbuf.copy_(host_frames[k % 4], non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_gbps = 50 * host_frames[0].numel() / (time.perf_counter() - th) / 1e9
 
     # ---- BASELINE cfg 2 as written (ONE panorama per forward): latency-bound, reported next to the batched figure
     one = rgb[:1].contiguous()
@@ -273,6 +332,26 @@ def main():
     b1_stream_ms = (time.perf_counter() - t1) / 100 * 1e3
     assert torch.equal(last1, net(one, confidence=True)), "graph-replayed and plain single-panorama forwards must agree bit for bit"
 
+    # ---- BASELINE cfg 3 as written: 1024x2048 ERP, nrows 6 (46 patches), 2-iteration spherical_fusion_iterative, one panorama
+    cfg3_ms = None
+    if rank == 0:
+        from omnifusion_amd.model.spherical_model_iterative import spherical_fusion as spherical_fusion_iterative
+        net3 = spherical_fusion_iterative(6, 46, (128, 128), FOV).cuda(local)
+        net3.load_state_dict(make_state_dict(42, 46, True))
+        x3 = torch.rand((1, 3, 1024, 2048), generator=g).to(dev)
+        for _ in range(3):
+            o3 = net3(x3, iter=2, confidence=False)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(10):
+            o3 = net3(x3, iter=2, confidence=False)
+        torch.cuda.synchronize()
+        cfg3_ms = (time.perf_counter() - t3) / 10 * 1e3
+        assert len(o3) == 2 and bool(torch.isfinite(o3[-1]).all())
+        configs["cfg3"]["ms_per_forward"] = cfg3_ms
+        configs["cfg3"]["note"] = "2-iteration iterative model at patch size 128 (SURVEY 0.1), one 1024x2048 panorama per forward; resample pair at 46 x 256^2, B = 1"
+        del net3, x3, o3
+
     out = {
         "metric": "panoramas/sec at 512x1024 ERP, N=18 256^2 patches; equi2pers+pers2equi GB/s vs HBM peak",
         "value": world * B * args.steps / dt, "unit": "panoramas/s",
@@ -291,9 +370,10 @@ def main():
                                "this rank's rate x ranks; outputs of the two modes are compared bit for bit in this run"},
         "stage_ms": {"equi2pers_P128": t_e2p * 1e3, "network": t_net * 1e3, "pers2equi_conf_P128": t_p2e * 1e3,
                      "note": "one forward at a time (stage events on the launch stream); in the timed region forwards overlap"},
-        "host_fed": {"panoramas_per_s_per_gpu": host_fed, "frac_of_resident": host_fed / (B * args.steps / dt),
+        "host_fed": {"panoramas_per_s_per_gpu": host_fed, "frac_of_resident": host_fed / (B * args.steps / dt), "batches": nfeed,
+                     "h2d_GBps": h2d_gbps, "h2d_GBps_needed": host_fed * ERP_H * ERP_W * 3 / 1e9,
                      "note": "inputs arrive as decoded uint8 BGR frames in pinned host memory (1.5 MB per panorama over PCIe), H2D + /255 + "
-                             "HWC->CHW on a side stream, triple-buffered (omnifusion_amd/data.py DeviceFeeder)"},
+                             "HWC->CHW on a side stream, triple-buffered (omnifusion_amd/data.py DeviceFeeder); steady state: timed after the first batches have been retired; h2d_GBps = pinned uint8 batches copied back to back on this box"},
         "batch1": {"ms_per_forward": b1_ms, "panoramas_per_s": 1e3 / b1_ms,
                    "note": "BASELINE cfg 2 literally: one 512x1024 panorama per forward on this GPU (latency of ~135 dependent launches)",
                    "stream_of_requests": {"ms_per_forward": b1_stream_ms, "panoramas_per_s": 1e3 / b1_stream_ms,
@@ -304,6 +384,8 @@ def main():
                                 "network section (conv_igemm_f32_kernel<...> dominant") + "; includes the stem/pool/upsample/LN/"
                                "attention/heads launches)",
                      "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+                     "frac_of_fp16_dense": (3 * tflops if f16x3 else tflops) / MFMA_F16_PEAK_TFLOPS,
+                     "frac_of_fp16_dense_algorithmic": tflops / MFMA_F16_PEAK_TFLOPS,
                      "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9,
                      "achieved_network_section_alone": NET_GFLOP_PER_PANO * B / t_net / 1e3,
                      "note": ("algorithmic (fp32-equivalent) flops of the network over the whole timed region (all launches of the steps); "
@@ -312,7 +394,7 @@ def main():
                               "(tools/dbg_mfma.py: 18-22 ns per 32x32x16 MFMA per SIMD chip-wide vs 13.5 ns on one CU): the "
                               "reachable ceiling is ~0.7 of `peak`") if f16x3 else
                              "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
-        "roofline_resample": {"bound": "hbm", "kernel": "e2p_box_kernel<float,2> + p2e_lds_kernel<float,8,false,2> at 18x256^2, B=%d (planar layout)" % B,
+        "roofline_resample": {"bound": "hbm", "kernel": "e2p_box_kernel<float,2,false> + p2e_lds_kernel<float,8,false,2> at 18x256^2, B=%d (planar layout)" % B,
                               "achieved": gbs_pair, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pair / HBM_PEAK_GBS,
                               # HBM bytes per launch pair from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE doubled as
                               # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), written by tools/pmc_traffic.sh
@@ -323,7 +405,9 @@ def main():
                                               "note": "the two operators on two streams (as consecutive pipelined forwards run them); "
                                                       "`achieved` / `frac` above are the strict figures: one launch after the other, HIP events per kernel"},
                               "equi2pers": {"us": r_e2p * 1e6, "bytes": bytes_e2p, "GB/s": bytes_e2p / r_e2p / 1e9},
-                              "pers2equi": {"us": r_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / r_p2e / 1e9}},
+                              "pers2equi": {"us": r_p2e * 1e6, "bytes": bytes_p2e, "GB/s": bytes_p2e / r_p2e / 1e9},
+                              "method": "one HIP event pair around 20+ back-to-back launches of the kernel, queued behind device-side spinning (agrees with rocprofv3 --kernel-trace: profiles/r03b_event_method.txt); mean of 3 such runs; measured before the matrix-bound steps"},
+        "configs": configs,
     }
     if rank == 0:
         out["cpu_baseline"] = None if args.no_cpu_baseline or world > 1 else cpu_baseline()

@@ -39,7 +39,7 @@ struct E2PArgs {
     int dbg;                   // tuning hook (OMNI_E2P_DBG): 1 = suppress stores, 2 = suppress box loads
     const float2* ixy;         // per-geometry table of clamped sampling coordinates [N][ph][pw] (e2p_lds_kernel), or null
     long long* trace;          // debug build, OMNI_E2P_DBG bit 16: per-block time stamps (omni_debug_set_trace)
-    int store_mode;            // option e2p_store: 0 plain | 1 nt | 2 sc1 (write-through, line dropped from the XCD's L2) | 3 sc0 sc1
+    int store_mode;            // option e2p_store: 0 plain | 1 non-temporal (default)
     PatchTab tab;
 };
 
@@ -624,30 +624,25 @@ __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __rest
 template <typename T> struct E2BStore4;
 template <> struct E2BStore4<float> {
     static __device__ __forceinline__ void st(float* p, const float (&r)[4]) { *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]); }
-    // cache-policy variants of the same 16-byte store (MI355X_MICROARCH.md, "stores of each flavour": plain / nt keep the line in the
-    // XCD's L2, sc1 writes through and drops it — the output is never re-read by this kernel, the ERP boxes are)
-    static __device__ __forceinline__ void st_mode(float* p, const float (&r)[4], int mode)
+    // non-temporal form: the output is never re-read by this kernel (the ERP boxes are), and at 16 panoramas — 327 MB per launch, more than
+    // the 256-MB memory-side cache — it is what keeps the launch at the 8-panorama rate (106 -> 64-74 us; 8 panoramas 38.5 -> 36.8).  sc1
+    // (write-through, line dropped from the XCD's L2) measured no better than plain stores.
+    static __device__ __forceinline__ void st_nt(float* p, const float (&r)[4])
     {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f v = {r[0], r[1], r[2], r[3]};
-        if (mode == 1)      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-        else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-        else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
     }
 };
 template <> struct E2BStore4<__half> {
     static __device__ __forceinline__ void st(__half* p, const float (&r)[4])
     { __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]); uint2 v; v.x = *reinterpret_cast<unsigned*>(&lo); v.y = *reinterpret_cast<unsigned*>(&hi); *reinterpret_cast<uint2*>(p) = v; }
-    static __device__ __forceinline__ void st_mode(__half* p, const float (&r)[4], int mode)
+    static __device__ __forceinline__ void st_nt(__half* p, const float (&r)[4])
     {
         __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]);
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
         const v2u v = {*reinterpret_cast<unsigned*>(&lo), *reinterpret_cast<unsigned*>(&hi)};
-        if (mode == 1)      asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-        else if (mode == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-        else if (mode == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        __builtin_nontemporal_store(v, reinterpret_cast<v2u*>(p));
     }
 };
 
@@ -715,24 +710,43 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
     const size_t bskip = out_bstride - (size_t)a.C * plane;
 
     if (fb_block) {
-        // ---- direct gathers (same taps, same fma chain) for a tile whose box does not fit a slot: planes [p_start, p_start + np)
+        // ---- direct gathers (same taps, same fma chain) for a tile whose box does not fit a slot: planes [p_start, p_start + np), FBU at a
+        // time — their pair loads are all in flight before the first is used (a block of these is a chain of memory round trips and
+        // nothing else)
         const T* img = (const T*)a.erp + (size_t)p_start * img_plane;
         T* dstb = out;
         int cc = c0p;
-        for (int p = 0; p < np; ++p) {
-            float r[NPX];
+        int g0[NPX], g1[NPX];
 #pragma unroll
-            for (int k = 0; k < NPX; ++k) {
-                const int sh = (gx0[k] + 1 >= W) ? 1 : 0;          // pair moved one column left (see above)
-                const int g0 = gy0[k] * W + gx0[k] - sh, g1 = gy1[k] * W + gx0[k] - sh;
-                const float v00 = Store<T>::ld(img + g0), v01 = Store<T>::ld(img + g0 + 1);
-                const float v10 = Store<T>::ld(img + g1), v11 = Store<T>::ld(img + g1 + 1);
-                r[k] = e2p_blend(v00, v01, v10, v11, w00[k], w01[k], w10[k], w11[k]);
+        for (int k = 0; k < NPX; ++k) {
+            const int sh = (gx0[k] + 1 >= W) ? 1 : 0;              // pair moved one column left (see above)
+            g0[k] = gy0[k] * W + gx0[k] - sh; g1[k] = gy1[k] * W + gx0[k] - sh;
+        }
+        constexpr int FBU = sizeof(T) == 4 ? 2 : 3;              // (three fp32 planes: 48 result registers, and the kernel spills at 128)
+        for (int p = 0; p < np; p += FBU) {
+            float v[FBU][NPX][4];
+#pragma unroll
+            for (int u = 0; u < FBU; ++u) {
+                const T* im = img + (size_t)min(u, np - 1 - p) * img_plane;      // (past the range: the last plane again, result unused)
+#pragma unroll
+                for (int k = 0; k < NPX; ++k) {
+                    Pair<T>::ld(im + g0[k], v[u][k][0], v[u][k][1]);
+                    Pair<T>::ld(im + g1[k], v[u][k][2], v[u][k][3]);
+                }
             }
-            if (ROWMAP) e2b_quad_transpose(r, lane);
-            E2BStore4<T>::st(dstb, r);
-            img += img_plane; dstb += plane;
-            if (++cc == a.C) { cc = 0; dstb += bskip; }
+#pragma unroll
+            for (int u = 0; u < FBU; ++u) {
+                if (p + u < np) {
+                    float r[NPX];
+#pragma unroll
+                    for (int k = 0; k < NPX; ++k) r[k] = e2p_blend(v[u][k][0], v[u][k][1], v[u][k][2], v[u][k][3], w00[k], w01[k], w10[k], w11[k]);
+                    if (ROWMAP) e2b_quad_transpose(r, lane);
+                    E2BStore4<T>::st(dstb, r);
+                    dstb += plane;
+                    if (++cc == a.C) { cc = 0; dstb += bskip; }
+                }
+            }
+            img += (size_t)FBU * img_plane;
         }
         return;
     }
@@ -781,7 +795,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
             if (ROWMAP) e2b_quad_transpose(r, lane);
         };
         auto store = [&](const float (&r)[NPX]) {
-            if (!OMNI_DBG(a, 1)) { if (a.store_mode) E2BStore4<T>::st_mode(dst, r, a.store_mode); else E2BStore4<T>::st(dst, r); }
+            if (!OMNI_DBG(a, 1)) { if (a.store_mode) E2BStore4<T>::st_nt(dst, r); else E2BStore4<T>::st(dst, r); }
             dst += plane;
             if (++cc == a.C) { cc = 0; dst += bskip; }
         };
@@ -1062,15 +1076,30 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
             // tiles that run at the same time read neighbouring boxes.
             std::vector<uint2> he((size_t)ntiles);
             OMNI_HIP(hipMemcpy(he.data(), tt.ent, sizeof(uint2) * (size_t)ntiles, hipMemcpyDeviceToHost));
+            // (round 3, option e2p_region = 1: 8 LATITUDE BANDS of equal estimated cost instead.  A pole tile reads a few ERP rows over hundreds
+            //  of columns; with the tiles of a cap spread over four sector XCDs — and the gather tiles over all eight — every XCD fetched the
+            //  polar rows of every plane: FETCH_SIZE 100 MB for the 50-MB input, 91 MB with half as many gather tiles.  A band keeps a cap on one XCD.)
             std::vector<std::vector<std::pair<unsigned, int>>> sec(8);
+            std::vector<int> region((size_t)ntiles, 0);
+            struct TI { int wid, xc, yc, ymin; bool fit; };
+            std::vector<TI> all((size_t)ntiles);
             for (int i = 0; i < (int)ntiles; ++i) {
-                if (!(he[i].x >> 31)) continue;
                 const int xs4 = (int)(he[i].y & 0xffff), ymin = (int)(he[i].y >> 16), bw = (int)(he[i].x & 4095) * epc, bh = (int)((he[i].x >> 12) & 4095);
                 int xc = xs4 + bw / 2; if (xc >= g->W) xc -= g->W;
-                const int yc = ymin + bh / 2;
-                const int sx = ((int)((long long)xc * 4 / g->W) & 3) + 4 * (yc * 2 >= g->H ? 1 : 0);
-                sec[sx].push_back({((unsigned)(ymin / 8) << 16) | (unsigned)xc, i});
+                all[i] = {i, xc, ymin + bh / 2, ymin, (he[i].x >> 31) != 0};
+                region[i] = ((int)((long long)xc * 4 / g->W) & 3) + 4 * (all[i].yc * 2 >= g->H ? 1 : 0);
             }
+            if (omni_options().e2p_region == 1) {
+                std::vector<TI> srt = all;
+                std::sort(srt.begin(), srt.end(), [](const TI& p, const TI& q) { return p.yc != q.yc ? p.yc < q.yc : p.xc < q.xc; });
+                auto cost = [](const TI& t) { return t.fit ? 166ll : 430ll; };       // a streaming tile vs a gather tile (8 blocks of 3 planes), 0.1 us
+                long long total = 0, run = 0;
+                for (auto& t : srt) total += cost(t);
+                for (auto& t : srt) { region[t.wid] = (int)std::min<long long>(7, run * 8 / std::max<long long>(1, total)); run += cost(t); }
+            }
+            for (int i = 0; i < (int)ntiles; ++i)
+                if (all[i].fit) sec[region[i]].push_back({((unsigned)(all[i].ymin / 8) << 16) | (unsigned)all[i].xc, i});
+            tt.h_region = region;
             size_t mx = 0;
             for (auto& v : sec) { std::sort(v.begin(), v.end()); mx = v.size() > mx ? v.size() : mx; }
             std::vector<int> ord(mx * 8, -1);
@@ -1113,7 +1142,7 @@ int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWor
     auto& tt = g->e2p_boxes[E];
     const OmniOptions& o = omni_options();
     const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : 12, split = o.e2p_split > 0 ? o.e2p_split : 2, fbp = o.e2p_fb_planes > 0 ? o.e2p_fb_planes : C;
-    const long long key = ((long long)planes << 32) | ((long long)(C & 0xff) << 24) | ((long long)(slots_cu & 0xff) << 16) | ((long long)(split & 0xff) << 8) | (long long)((fbp & 0xf) << 4 | (nbmax & 0xf));
+    const long long key = ((long long)planes << 32) | ((long long)(C & 0xff) << 24) | ((long long)(slots_cu & 0xff) << 16) | ((long long)(split & 0xff) << 8) | (long long)((fbp & 0xf) << 4 | (nbmax & 0xf)) | ((long long)(o.e2p_fb_pos & 3) << 54) | ((long long)((o.e2p_full + 1) & 0xff) << 56);
     std::lock_guard<std::mutex> lk(g->work_mu);
     for (auto& w : tt.work) if (w.key == key) { out.dev = w.dev; out.nblocks = w.nblocks; return OMNI_OK; }
     const int slots_xcd = slots_cu * (omni_num_cus() / 8);
@@ -1127,18 +1156,24 @@ int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWor
         const int nt = (int)tiles[x].size();
         // whole tiles while they fill the slots exactly once; the rest in `parts` ranges (all of one range first: blocks that start together run the same planes)
         const int nfull = nt <= slots_xcd ? nt : (o.e2p_full >= 0 ? std::min(nt, slots_xcd * o.e2p_full / 100) : slots_xcd);
+        auto gathers = [&]() {
+            for (int f = 0; f < tt.nfb; ++f)
+                if ((tt.h_region[tt.h_fb[f]] & 7) == x)
+                    for (int p0 = 0; p0 < planes; p0 += fbp) col[x].push_back(seg(tt.h_fb[f], true, p0, std::min(fbp, planes - p0)));
+        };
+        // (an XCD with fewer tiles than slots has room for its gather blocks beside them: first, not as a tail — P = 128: 25.3 -> 22.4 us)
+        const int fb_pos = nt < slots_xcd && o.e2p_fb_pos == 0 ? 3 : o.e2p_fb_pos;
+        if (fb_pos == 3) gathers();
         for (int i = 0; i < nfull; ++i) col[x].push_back(seg(tiles[x][i], false, 0, planes));
+        if (fb_pos == 1) gathers();
         for (int q = 0; q < parts; ++q) {
             const int p0 = (int)((long long)planes * q / parts), p1 = (int)((long long)planes * (q + 1) / parts);
             for (int i = nfull; i < nt; ++i) col[x].push_back(seg(tiles[x][i], false, p0, p1 - p0));
+            if (fb_pos == 2 && q == 0) gathers();
         }
+        if (fb_pos == 0) gathers();
     }
-    // gather tiles: ranges of fbp planes, spread over the XCDs, last
-    {
-        int x = 0;
-        for (int f = 0; f < tt.nfb; ++f)
-            for (int p0 = 0; p0 < planes; p0 += fbp) { col[x].push_back(seg(tt.h_fb[f], true, p0, std::min(fbp, planes - p0))); x = (x + 1) & 7; }
-    }
+    // (gather tiles: ranges of fbp planes, spread over the XCDs — behind the whole tiles or last, see above)
     size_t mx = 0;
     for (auto& c : col) mx = std::max(mx, c.size());
     std::vector<uint4> tab(mx * 8, make_uint4(0u, 0u, 0u, 0u));

@@ -36,11 +36,13 @@ struct OmniOptions {
     int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 1: pers2equi backward by global atomics (the round-1 kernel) instead of patch-tile gathers
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
-    int e2p_store;        // OMNI_E2P_STORE      cache policy of the patch stores of the equi2pers box kernel: 0 plain | 1 nt (default: 106 -> 74 us at 16 panoramas, where the 327 MB of a launch exceed the 256-MB memory-side cache) | 2 sc1 | 3 sc0 sc1
+    int e2p_store;        // OMNI_E2P_STORE      patch stores of the equi2pers box kernel: 0 plain | 1 non-temporal (default: 106 -> 64-74 us at 16 panoramas, whose 327 MB per launch exceed the 256-MB memory-side cache)
     int e2p_slots;        // OMNI_E2P_SLOTS      wave slots per CU the equi2pers work table plans for (0: 12, what the 12-KiB ring admits)
     int e2p_split;        // OMNI_E2P_SPLIT      plane ranges a tile beyond the first round of slots is cut into (0: 2)
     int e2p_full;         // OMNI_E2P_FULL       -1: one whole tile per slot first; else that percentage of the slots
     int e2p_fb_planes;    // OMNI_E2P_FB_PLANES  planes per gather block of a pole tile (0: C)
+    int e2p_region;       // OMNI_E2P_REGION     which tiles share an XCD: 0 ERP sectors (4 longitudes x 2 hemispheres) | 1 eight latitude bands of equal cost
+    int e2p_fb_pos;       // OMNI_E2P_FB_POS     where the gather blocks go: 0 last | 1 behind the whole tiles | 2 behind the first plane range of the cut tiles
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
@@ -98,7 +100,7 @@ struct omni_geometry {
     struct E2PWorkTab { long long key; uint4* dev; int nblocks; };
     struct E2PTiles { uint2* ent; int* fb; int nfb; int max_chunks; int tw, th, tx, ty; int ok;
                       int* order; int norder;                 // order: LDS-path tiles grouped by ERP longitude sector, one sector per XCD (-1 = padding)
-                      std::vector<uint2> h_ent; std::vector<int> h_order, h_fb;   // host copies: the work tables are built from them
+                      std::vector<uint2> h_ent; std::vector<int> h_order, h_fb, h_region;   // host copies: the work tables are built from them
                       std::vector<E2PWorkTab> work; } e2p_boxes[2];               // work tables of e2p_box_kernel, one per plane count (omni_equi2pers.hip)
     std::mutex work_mu;
     int* e2p_fb_tiles;             // equi2pers backward: (patch, 32x32 tile) ids whose ERP footprint does not fit the LDS box

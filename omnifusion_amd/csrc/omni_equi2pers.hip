@@ -1141,8 +1141,9 @@ int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWor
     omni_geometry* g = const_cast<omni_geometry*>(gc);             // (the cache is a mutable part of the handle)
     auto& tt = g->e2p_boxes[E];
     const OmniOptions& o = omni_options();
-    const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : 12, split = o.e2p_split > 0 ? o.e2p_split : 2, fbp = o.e2p_fb_planes > 0 ? o.e2p_fb_planes : C;
-    const long long key = ((long long)planes << 32) | ((long long)(C & 0xff) << 24) | ((long long)(slots_cu & 0xff) << 16) | ((long long)(split & 0xff) << 8) | (long long)((fbp & 0xf) << 4 | (nbmax & 0xf)) | ((long long)(o.e2p_fb_pos & 3) << 54) | ((long long)((o.e2p_full + 1) & 0xff) << 56);
+    const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : 12, split = o.e2p_split > 0 ? o.e2p_split : 3,
+              fbp = o.e2p_fb_planes > 0 && o.e2p_fb_planes < 90 ? o.e2p_fb_planes : std::min(tt.norder < slots_cu * omni_num_cus() ? 6 : 12, planes);   // (shorter where the launch is under one round: P = 128)
+    const long long key = ((long long)planes << 32) | ((long long)(C & 0xff) << 24) | ((long long)(slots_cu & 0xff) << 16) | ((long long)(split & 0xff) << 8) | (long long)((fbp & 0xf) << 4 | (nbmax & 0xf)) | ((long long)(o.e2p_fb_planes >= 98 ? o.e2p_fb_planes - 97 : 0) << 52) | ((long long)(o.e2p_fb_pos & 3) << 54) | ((long long)((o.e2p_full + 1) & 0xff) << 56);
     std::lock_guard<std::mutex> lk(g->work_mu);
     for (auto& w : tt.work) if (w.key == key) { out.dev = w.dev; out.nblocks = w.nblocks; return OMNI_OK; }
     const int slots_xcd = slots_cu * (omni_num_cus() / 8);
@@ -1155,15 +1156,21 @@ int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWor
     for (int x = 0; x < 8; ++x) {
         const int nt = (int)tiles[x].size();
         // whole tiles while they fill the slots exactly once; the rest in `parts` ranges (all of one range first: blocks that start together run the same planes)
-        const int nfull = nt <= slots_xcd ? nt : (o.e2p_full >= 0 ? std::min(nt, slots_xcd * o.e2p_full / 100) : slots_xcd);
+        int nfb_x = 0;
+        for (int f = 0; f < tt.nfb; ++f) if ((tt.h_region[tt.h_fb[f]] & 7) == x) nfb_x += (planes + fbp - 1) / fbp;
+        const int first = o.e2p_fb_pos == 0 ? std::max(0, slots_xcd - nfb_x) : slots_xcd;   // slots left for whole tiles in round one
+        const int nfull = nt <= first ? nt : (o.e2p_full >= 0 ? std::min(nt, first * o.e2p_full / 100) : first);
         auto gathers = [&]() {
+            if (o.e2p_fb_planes == 99) return;                         // (tuning: no gather blocks at all — results wrong, timing of the streaming part)
             for (int f = 0; f < tt.nfb; ++f)
                 if ((tt.h_region[tt.h_fb[f]] & 7) == x)
                     for (int p0 = 0; p0 < planes; p0 += fbp) col[x].push_back(seg(tt.h_fb[f], true, p0, std::min(fbp, planes - p0)));
         };
-        // (an XCD with fewer tiles than slots has room for its gather blocks beside them: first, not as a tail — P = 128: 25.3 -> 22.4 us)
-        const int fb_pos = nt < slots_xcd && o.e2p_fb_pos == 0 ? 3 : o.e2p_fb_pos;
+        // (the gather blocks go FIRST, 12 planes each: latency-bound blocks about as long as a whole streaming tile, on 1 slot in 13 — as a tail
+        //  of 3-plane blocks they cost 5 us: 36.4 -> 33.4 us, 16 panoramas 69 -> 64 us)
+        const int fb_pos = o.e2p_fb_pos == 0 ? 3 : o.e2p_fb_pos;   // 3 = first (default): the longest blocks of the launch, beside the whole tiles
         if (fb_pos == 3) gathers();
+        if (o.e2p_fb_planes == 98) { gathers(); continue; }            // (tuning: ONLY the gather blocks)
         for (int i = 0; i < nfull; ++i) col[x].push_back(seg(tiles[x][i], false, 0, planes));
         if (fb_pos == 1) gathers();
         for (int q = 0; q < parts; ++q) {
@@ -1171,7 +1178,7 @@ int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWor
             for (int i = nfull; i < nt; ++i) col[x].push_back(seg(tiles[x][i], false, p0, p1 - p0));
             if (fb_pos == 2 && q == 0) gathers();
         }
-        if (fb_pos == 0) gathers();
+        if (fb_pos == 4) gathers();
     }
     // (gather tiles: ranges of fbp planes, spread over the XCDs — behind the whole tiles or last, see above)
     size_t mx = 0;

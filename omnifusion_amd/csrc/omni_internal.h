@@ -38,11 +38,11 @@ struct OmniOptions {
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
     int e2p_store;        // OMNI_E2P_STORE      patch stores of the equi2pers box kernel: 0 plain | 1 non-temporal (default: 106 -> 64-74 us at 16 panoramas, whose 327 MB per launch exceed the 256-MB memory-side cache)
     int e2p_slots;        // OMNI_E2P_SLOTS      wave slots per CU the equi2pers work table plans for (0: 12, what the 12-KiB ring admits)
-    int e2p_split;        // OMNI_E2P_SPLIT      plane ranges a tile beyond the first round of slots is cut into (0: 2)
+    int e2p_split;        // OMNI_E2P_SPLIT      plane ranges a tile beyond the first round of slots is cut into (0: 3)
     int e2p_full;         // OMNI_E2P_FULL       -1: one whole tile per slot first; else that percentage of the slots
-    int e2p_fb_planes;    // OMNI_E2P_FB_PLANES  planes per gather block of a pole tile (0: C)
+    int e2p_fb_planes;    // OMNI_E2P_FB_PLANES  planes per gather block of a pole tile (0: 12)
     int e2p_region;       // OMNI_E2P_REGION     which tiles share an XCD: 0 ERP sectors (4 longitudes x 2 hemispheres) | 1 eight latitude bands of equal cost
-    int e2p_fb_pos;       // OMNI_E2P_FB_POS     where the gather blocks go: 0 last | 1 behind the whole tiles | 2 behind the first plane range of the cut tiles
+    int e2p_fb_pos;       // OMNI_E2P_FB_POS     where the gather blocks go: 0 / 3 first | 1 behind the whole tiles | 2 behind the first plane range of the cut tiles | 4 last
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8

@@ -674,14 +674,72 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
     const int xs4 = (int)(e.y & 0xffff), ymin = (int)(e.y >> 16), bw4 = (int)(e.x & 4095), bh = (int)((e.x >> 12) & 4095);
     const int pitch = bw4 * EPC;
 
+    // ---- the sampling coordinates of my NPX samples go out FIRST (plain loads, hand-counted: the compiler does not see them), the first
+    // NB boxes right behind them, and the taps are computed while both travel: a block's set-up was two dependent round trips in front
+    // of its first DMA (work entry -> coordinates; 2.3 us of a third-of-a-tile block's 5.6 us), now the boxes ride on the second
+    typedef float e2b_v2f __attribute__((ext_vector_type(2)));
+    e2b_v2f cxy[NPX];
+    const bool tab = a.ixy != nullptr;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int hh = ROWMAP ? hb + 2 * k : hb, ww = ROWMAP ? w : w + k;
+        if (tab) {
+            const float2* q = a.ixy + ((size_t)n * a.ph + hh) * a.pw + ww;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(cxy[k]) : "v"(q) : "memory");
+        } else {
+            float ix, iy;
+            e2p_sample_xy(a, n, hh, ww, ix, iy);
+            cxy[k].x = ix; cxy[k].y = iy;
+        }
+    }
+    const int plane = a.ph * a.pw;
+    const size_t img_plane = (size_t)H * W;
+    const e2b_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.erp), (short)0, (int)tensor_bytes, 0x00020000);
+    const unsigned rowb = (unsigned)W * (unsigned)sizeof(T), planeb = (unsigned)img_plane * (unsigned)sizeof(T);
+    const int nchunk = bw4 * bh, njj = (nchunk + 63) >> 6;
+    unsigned g[E2B_NJMAX];                                          // byte offset of my chunk of piece q inside an image plane
+    auto prologue = [&]<int NJ>(std::integral_constant<int, NJ>) {
+        constexpr int NBR = E2B_RING_KB / NJ >= 4 ? 4 : E2B_RING_KB / NJ >= 2 ? 2 : 1;
+        constexpr int NB = NBR < NBMAX ? NBR : NBMAX;
+        constexpr unsigned slot_bytes = NJ * 1024u;
+        const float rbw = __builtin_amdgcn_rcpf((float)bw4);
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int qc = q * 64 + lane;
+            const int rr = (int)(((float)qc + 0.5f) * rbw);                    // qc / bw4, exact for qc, bw4 <= 4096
+            int gx = xs4 + (qc - rr * bw4) * EPC;
+            if (gx >= W) gx -= W;                                                 // the box wraps at the seam
+            g[q] = qc < nchunk ? (unsigned)(ymin + rr) * rowb + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;   // past the end: zeros
+        }
+        if (!OMNI_DBG(a, 2)) {
+#pragma unroll
+            for (int d = 0; d < NB; ++d) {
+                const unsigned so = (unsigned)(p_start + d) * planeb;
+#pragma unroll
+                for (int q = 0; q < NJ; ++q) e2b_dma16(rs, e2b_smem + (unsigned)d * slot_bytes + q * 1024, g[q], so);
+            }
+            e2b_wait_vm<NB * NJ>();                                 // the coordinates are older than the NB * NJ pieces: they have landed
+        } else e2b_wait_vm<0>();
+    };
+    if (fb_block) e2b_wait_vm<0>();
+    else switch (njj) {
+    case 1: prologue(std::integral_constant<int, 1>()); break;
+    case 2: prologue(std::integral_constant<int, 2>()); break;
+    case 3: prologue(std::integral_constant<int, 3>()); break;
+    case 4: prologue(std::integral_constant<int, 4>()); break;
+    case 5: prologue(std::integral_constant<int, 5>()); break;
+    case 6: prologue(std::integral_constant<int, 6>()); break;
+    case 7: prologue(std::integral_constant<int, 7>()); break;
+    default: prologue(std::integral_constant<int, 8>()); break;
+    }
     // ---- taps of my NPX samples: LDS element offsets inside the box + ATen's four weights
     int r0[NPX], r1[NPX];
     float w00[NPX], w01[NPX], w10[NPX], w11[NPX];
     int gx0[NPX], gy0[NPX], gy1[NPX];                              // (fallback path: absolute taps)
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
-        float ix, iy;
-        if (ROWMAP) e2b_xy(a, n, hb + 2 * k, w, ix, iy); else e2b_xy(a, n, hb, w + k, ix, iy);
+        asm volatile("" : "+v"(cxy[k]));                           // (use only behind the wait above)
+        const float ix = cxy[k].x, iy = cxy[k].y;
         const float fx = floorf(ix), fy = floorf(iy);
         const int x0 = (int)fx, y0 = (int)fy;
         const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
@@ -700,8 +758,6 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         r0[k] = (y0 - ymin) * pitch + c0;
         r1[k] = (y1 - ymin) * pitch + c0;
     }
-    const int plane = a.ph * a.pw;
-    const size_t img_plane = (size_t)H * W;
     const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
     // ROWMAP: after the quad transpose lane l holds row hb + 2 (l % 4), columns 4 ((l % 32) / 4) .. +3 of the tile
     const int b0 = p_start / a.C, c0p = p_start - b0 * a.C;        // batch item / channel of my first plane
@@ -750,11 +806,8 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         }
         return;
     }
-    // every ordinary load has been consumed (the taps depend on them): nothing but LDS-DMA pieces and stores below
-    if (OMNI_DBG(a, 16)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr1 = wall_clock64(); }
-    const e2b_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.erp), (short)0, (int)tensor_bytes, 0x00020000);
-    const unsigned rowb = (unsigned)W * (unsigned)sizeof(T), planeb = (unsigned)img_plane * (unsigned)sizeof(T);
-    const int nchunk = bw4 * bh, njj = (nchunk + 63) >> 6;
+    // nothing but LDS-DMA pieces and stores below
+    if (OMNI_DBG(a, 16)) tr1 = wall_clock64();
 
     auto run = [&]<int NJ>(std::integral_constant<int, NJ>) {
         // ring of E2B_RING_KB 1-KiB pieces per wave: a box of NJ pieces gets NB = min(NBMAX, largest power of two <= RING / NJ) slots of
@@ -762,18 +815,6 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         constexpr int NBR = E2B_RING_KB / NJ >= 4 ? 4 : E2B_RING_KB / NJ >= 2 ? 2 : 1;
         constexpr int NB = NBR < NBMAX ? NBR : NBMAX;
         constexpr unsigned slot_bytes = NJ * 1024u;
-        unsigned g[NJ];                                             // byte offset of my chunk of piece q inside an image plane
-        {
-            const float rbw = __builtin_amdgcn_rcpf((float)bw4);
-#pragma unroll
-            for (int q = 0; q < NJ; ++q) {
-                const int qc = q * 64 + lane;
-                const int rr = (int)(((float)qc + 0.5f) * rbw);                    // qc / bw4, exact for qc, bw4 <= 4096
-                int gx = xs4 + (qc - rr * bw4) * EPC;
-                if (gx >= W) gx -= W;                                                 // the box wraps at the seam
-                g[q] = qc < nchunk ? (unsigned)(ymin + rr) * rowb + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;   // past the end: zeros
-            }
-        }
         auto issue = [&](int p, int slot) {
             if (OMNI_DBG(a, 2)) return;
             unsigned char* dst = e2b_smem + (unsigned)slot * slot_bytes;
@@ -804,9 +845,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         //                                             last group   (NB-1) + (NB-1-s) NJ   |  only group  (NB-1-s) NJ + s
         // (round 3: issuing a stage's refill BEFORE its store, so that a write acknowledge has two stage-times instead of one before a
         //  counted wait can stall on it, measured no different: 39.3 vs 38.5 us — the stores are not what the waits wait for)
-        const int groups = np / NB;
-#pragma unroll
-        for (int d = 0; d < NB; ++d) issue(d, d);
+        const int groups = np / NB;                                 // (the first NB stages went out in the prologue)
         auto group = [&]<int KIND>(std::integral_constant<int, KIND>, int p0) {
             [&]<int... S>(std::integer_sequence<int, S...>) {
                 (([&] {

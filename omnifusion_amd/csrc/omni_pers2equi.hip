@@ -24,6 +24,7 @@
 //
 // HBM-bound: algorithmic bytes B*C*(ph*pw*N + H*W)*sizeof(T); tables read: 8 B per tile.
 #include <stdio.h>
+#include <string.h>
 #include <utility>
 #include <vector>
 #include <algorithm>
@@ -274,7 +275,10 @@ __global__ __launch_bounds__(256) void p2e_kernel(P2EArgs a, int tiles_per_row4,
 constexpr int P2E_TH = 4, P2E_TW = 32;          // ERP tile of one wave: NPX = TH/2 pixels per lane (lane -> column lane%32, rows lane/32 + 2k)
 constexpr int P2E_NPX = P2E_TH / 2;
 constexpr int P2E_MAXC = 12;                    // table entries (covering patches) per tile
-constexpr int P2E_ENT = P2E_MAXC + 1;           // uint2 per block slot of the ORDERED table the kernels read: the entries, then {tile id | -1, 0}
+// The ORDERED table the kernel reads: per block slot P2E_REC records of 32 bytes — {tile id | -1, covering patches, 0...}, then per covering
+// patch {entry x, entry y, sin l0, cos l0 | sin p1, cos p1, 0, 0} (the patch constants ride with the entry: one scalar load per patch, issued
+// one patch AHEAD, instead of a table entry and then four dependent loads from the argument segment in front of every patch), one spare.
+constexpr int P2E_REC = P2E_MAXC + 2;
 constexpr int P2E_NJMAX = 8;                    // 1-KiB DMA pieces per box at most: boxes up to 8 KiB
 constexpr int P2E_MAX_CHUNKS = 64 * P2E_NJMAX;
 
@@ -401,8 +405,9 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     if (OMNI_DBG(a, 16)) tr0 = wall_clock64();
     // block -> tile: the ordered table of the geometry (omni_p2e_build_tiles: whole bands of tile rows per XCD, and inside an XCD the
     // tiles dealt so that every CU gets the same amount of work; slot blockIdx.x holds the tile's entries and its id)
-    const uint2* __restrict__ te = tiles + (size_t)blockIdx.x * P2E_ENT;
-    const int wid = (int)te[P2E_MAXC].x;
+    const uint4* __restrict__ sl = reinterpret_cast<const uint4*>(tiles) + (size_t)blockIdx.x * (2 * P2E_REC);
+    const uint4 hd = sl[0];
+    const int wid = (int)hd.x;
     if (wid < 0) return;                                                            // padding slot (block-uniform)
     const int ti = wid / tiles_x, tj = wid - ti * tiles_x;
     const int col = lane & 31, rsub = lane >> 5;
@@ -419,7 +424,8 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     float2 rt[NPX];
 #pragma unroll
     for (int k = 0; k < NPX; ++k) rt[k] = a.row_trig[min(ti * P2E_TH + rsub + 2 * k, a.H - 1)];
-    const int ncand = (int)(te[0].x >> 26);
+    const int ncand = (int)hd.y;
+    uint4 ea = sl[2], eb = sl[3];                                  // record of the first patch
     unsigned poff_l;                                               // lane p: byte offset of plane p_begin + p (< 2^31, host-checked)
     {
         const int p = p_begin + min(lane, PL - 1);
@@ -442,8 +448,9 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
     }
 
     for (int c = 0; c < ncand; ++c) {
-        const uint2 e = te[c];
-        const unsigned e0 = e.x, e1 = e.y;
+        const uint4 na = sl[2 * (c + 2)], nb4 = sl[2 * (c + 2) + 1];   // the NEXT patch's record travels under this patch's stages
+        const unsigned e0 = ea.x, e1 = ea.y;
+        const float sl0 = __uint_as_float(ea.z), cl0 = __uint_as_float(ea.w), sp = __uint_as_float(eb.x), cp = __uint_as_float(eb.y);
         const int n = e0 & 63, bw4 = (e0 >> 6) & 1023, xa = e1 & 0xffff, ymin = e1 >> 16;
         const int nchunk = bw4 * (int)((e0 >> 16) & 1023), njj = (nchunk + 63) >> 6;
         const unsigned base = (unsigned)n * sNb + (unsigned)ymin * sYb + (unsigned)xa * (unsigned)sizeof(T);
@@ -485,13 +492,13 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
         const int pitch = bw4 * EPC;
         int r0[NPX], r1[NPX];
         float wa[NPX], wb[NPX], wc[NPX], wd[NPX];
-        float cd, sd;
-        p2e_lon(a, n, ct.x, ct.y, cd, sd);
+        const float cd = ct.y * cl0 + ct.x * sl0;                   // p2e_lon with the record's constants (ct = (sin lon, cos lon)): cos(lon - l0)
+        const float sd = ct.x * cl0 - ct.y * sl0;                   //                                                          sin(lon - l0)
 #pragma unroll
         for (int k = 0; k < NPX; ++k) {
             Taps t;
             if (OMNI_DBG(a, 1)) { t.x0 = xa + 1; t.x1 = xa + 2; t.y0 = ymin; t.y1 = ymin; t.wa = t.wb = t.wc = t.wd = 0.25f * rt[k].x; }
-            else p2e_taps_cs(a, n, rt[k].x, rt[k].y, cd, sd, t);
+            else p2e_taps_core(a, sp, cp, rt[k].x, rt[k].y, cd, sd, t);
             const float wsum = (t.wa + t.wb) + (t.wc + t.wd);           // all >= 0 after the threshold
             l1[k] += wsum;
             // the pair (x0, x0+1) of both tap rows; at the right patch edge (x1 == x0: wa == wb == 0, see p2e_taps_cs) the pair is
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
         default: stages(std::integral_constant<int, 8>()); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the ring is a DMA target again for the next patch
+        ea = na; eb = nb4;
     }
     // ---- normalise and store (pers2equi_v3.py:192-196; K11: spherical_model.py:310-311)
     const size_t erp_plane = (size_t)a.H * a.W;
@@ -821,15 +829,24 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
             }
             const size_t rounds = (mx + 31) / 32;
             tt.nslots = (int)(rounds * 32 * 8);
-            std::vector<uint2> ord((size_t)tt.nslots * P2E_ENT, make_uint2(0u, 0u));
-            for (int s2 = 0; s2 < tt.nslots; ++s2) ord[(size_t)s2 * P2E_ENT + P2E_MAXC].x = 0xffffffffu;
+            std::vector<uint2> ord((size_t)tt.nslots * 4 * P2E_REC, make_uint2(0u, 0u));       // (a 32-byte record = 4 uint2)
+            for (int s2 = 0; s2 < tt.nslots; ++s2) ord[(size_t)s2 * 4 * P2E_REC].x = 0xffffffffu;
+            auto fbits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
             for (int xcd = 0; xcd < 8; ++xcd)
                 for (size_t k = 0; k < per[xcd].size(); ++k) {
                     const size_t r = k / 32, i = k % 32, pos = r * 32 + ((r & 1) ? 31 - i : i);
                     const size_t slot = pos * 8 + (size_t)xcd;
                     const int wid = per[xcd][k];
-                    for (int c = 0; c < P2E_MAXC; ++c) ord[slot * P2E_ENT + c] = he[(size_t)wid * P2E_MAXC + c];
-                    ord[slot * P2E_ENT + P2E_MAXC] = make_uint2((unsigned)wid, 0u);
+                    uint2* rec = ord.data() + slot * 4 * P2E_REC;
+                    const int cnt = (int)(he[(size_t)wid * P2E_MAXC].x >> 26);
+                    rec[0] = make_uint2((unsigned)wid, (unsigned)cnt);
+                    for (int c = 0; c < P2E_MAXC; ++c) {
+                        const uint2 e2 = he[(size_t)wid * P2E_MAXC + c];
+                        const int n = (int)(e2.x & 63u);
+                        rec[4 * (c + 1) + 0] = e2;
+                        rec[4 * (c + 1) + 1] = make_uint2(fbits(g->p2e.slam[n]), fbits(g->p2e.clam[n]));
+                        rec[4 * (c + 1) + 2] = make_uint2(fbits(g->p2e.sphi[n]), fbits(g->p2e.cphi[n]));
+                    }
                 }
             if (hipMalloc((void**)&tt.ord, sizeof(uint2) * ord.size()) != hipSuccess ||
                 hipMemcpy(tt.ord, ord.data(), sizeof(uint2) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: order table"); }

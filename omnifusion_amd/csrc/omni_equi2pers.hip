@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         if (!OMNI_DBG(a, 2)) {
 #pragma unroll
             for (int d = 0; d < NB; ++d) {
-                const unsigned so = (unsigned)(p_start + d) * planeb;
+                const unsigned so = OMNI_DBG(a, 32) ? 0u : (unsigned)(p_start + d) * planeb;       // (debug bit 32: every plane reads plane 0 — no input traffic)
 #pragma unroll
                 for (int q = 0; q < NJ; ++q) e2b_dma16(rs, e2b_smem + (unsigned)d * slot_bytes + q * 1024, g[q], so);
             }
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         auto issue = [&](int p, int slot) {
             if (OMNI_DBG(a, 2)) return;
             unsigned char* dst = e2b_smem + (unsigned)slot * slot_bytes;
-            const unsigned so = (unsigned)(p_start + p) * planeb;
+            const unsigned so = OMNI_DBG(a, 32) ? 0u : (unsigned)(p_start + p) * planeb;
 #pragma unroll
             for (int q = 0; q < NJ; ++q) e2b_dma16(rs, dst + q * 1024, g[q], so);
         };

@@ -171,6 +171,11 @@ class Engine:
             out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
         b = _p(self.w[key + ".b"]) if bias else None
+        late_post = None
+        if post is not None and (S > 1 or not self.sh or out_f32):
+            # the fused `+ post` epilogue exists for un-split SH launches only (omni_conv2d_sh_f16x3_post_ws rejects splitk > 1): a shape
+            # whose plan splits K (few rows: small patches, nrows = 3, a lone panorama) adds it as a pass of its own instead
+            late_post, post = post, None
         if self.sh and post is not None:                            # `+ post` after the activation, inside the epilogue (SH mode, never split)
             rc = lib.omni_conv2d_sh_f16x3_post_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), 0 if out_f32 else 1,
                                                   M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb),
@@ -182,6 +187,9 @@ class Engine:
             rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), b, _p(res), _p(out), M, H, Wd, C1, C2, Cout,
                                              k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "conv2d " + key)
+        if late_post is not None:
+            _lib.check((lib.omni_add_period_sh if self.sh else lib.omni_add_period_f32)(
+                _p(out), _p(late_post), ctypes.c_size_t(out.numel()), ctypes.c_size_t(late_post.numel()), self._s), "add post " + key)
         return out
 
     NOMINAL_BATCH = 8

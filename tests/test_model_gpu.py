@@ -390,6 +390,47 @@ def test_iterative_model_nrows6_golden():
     assert np.abs(o[1].cpu().numpy() - g["it1"]).max() <= 1e-3
 
 
+def test_iterative_model_config3_size():
+    """BASELINE config 3 verbatim: ONE 1024x2048 panorama, nrows = 6 (46 patches), the 2-iteration iterative model at patch size 128
+    (SURVEY 0.1), confidence=False as test.py:198 calls it — against the torch fp32 oracle (oracle/model_ref.py), every iteration, with
+    the outlier-bounded gate of SURVEY 8d (at this ERP width two fp32 evaluations of the geometry differ at isolated pixels)."""
+    _, spherical_fusion_it, make_state_dict = _nets()
+    from oracle import model_ref
+    from _util import assert_close_outliers
+    sd = make_state_dict(42, 46, True)
+    net = spherical_fusion_it(6, 46, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(sd)
+    rgb = torch.from_numpy(smooth_erp(78, 1, 3, 1024, 2048))
+    outs = net(rgb.to(DEV), iter=2)
+    assert isinstance(outs, list) and len(outs) == 2 and outs[1].shape == (1, 1, 1024, 2048)
+    ref = model_ref.spherical_fusion_iterative_forward(sd, rgb, 2, nrows=6, patch_size=128, fov=(80, 80), confidence=False)
+    for k in range(2):
+        o, r = outs[k].cpu().numpy(), ref[k].numpy()
+        assert_close_outliers(o, r, tol=1e-3, max_tol=2e-2, frac=1e-5, what=f"cfg3 iteration {k} vs oracle", ref_nan_max=8)
+        ok = np.isfinite(r)
+        assert np.quantile(np.abs(o - np.where(ok, r, o))[ok], 0.9999) < 2e-4
+
+
+def test_point_feat_fold_with_a_split_k_plan():
+    """the fused `+ point_feat` epilogue exists for un-split launches only; a shape whose plan splits K (few rows per
+    panorama) must take the separate add — forced here by planning a lone panorama's splits for a batch of ONE."""
+    from omnifusion_amd.model._engine import Engine
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(3, 10, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 10, False))
+    rgb = torch.from_numpy(smooth_erp(79, 1, 3, 64, 128)).to(DEV)
+    ref = net(rgb, confidence=True).clone()
+    old = Engine.SINGLE_BATCH
+    try:
+        Engine.SINGLE_BATCH = 1                                    # 10 x 32 x 32 rows: layer1's last convolution now plans S > 1
+        out = net(rgb, confidence=True)
+        Engine.fold_point_feat = False
+        out2 = net(rgb, confidence=True)
+    finally:
+        Engine.SINGLE_BATCH = old; Engine.fold_point_feat = True
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() < 5e-5 and (out - out2).abs().max().item() < 5e-5
+
+
 def test_graphed_forward_matches_eager():
     """hipGraph replay of the whole launch sequence gives the same bits as the eager forward."""
     spherical_fusion, _, make_state_dict = _nets()

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from oracle import c_oracle as co
-from _util import golden, GOLDEN, rng_uniform, assert_close_outliers
+from _util import golden, GOLDEN, rng_uniform, assert_close_outliers, assert_outliers_at_mask_edges, mask_edge_neighbourhood
 
 
 @pytest.mark.parametrize("name", ["G1_equi2pers_n4", "G2_equi2pers_n6", "G2b_equi2pers_n3",
@@ -143,3 +143,26 @@ def test_known_answers_config3_and_nan_quirk():
     assert abs(np.nansum(e.astype(np.float64)) - float(g["erp_sum"])) < 0.5
     sub = e[:, :, ::8, ::8]
     np.testing.assert_allclose(sub, g["erp_sub"], atol=2e-4)
+
+
+def test_outliers_only_at_validity_mask_edges():
+    """The gate the GPU tests apply to every pers2equi comparison: a pixel may differ by more than round-off only within one pixel of an
+    edge of the oracle's own per-patch validity mask.  Here: the helper itself (a planted error away from every edge is caught, one on
+    an edge is not) and the C oracle against the reference's output at the known-answer size."""
+    g = golden("G3_pers2equi_n4")
+    fov = tuple(float(v) for v in g["fov"]); P = g["pers"].shape[2]; H, W = (int(v) for v in g["erp_size"])
+    tab = co.pers2equi_tables(fov, 4, (P, P), (H, W))
+    near = mask_edge_neighbourhood(tab["mask"])
+    assert 0.0 < near.mean() < 1.0
+    out = co.pers2equi(g["pers"], fov, 4, (P, P), (H, W))
+    assert_outliers_at_mask_edges(out, g["erp"], tab["mask"], 2e-4)
+    y, x = np.argwhere(~near)[0]
+    bad = g["erp"].copy(); bad[0, 0, y, x] += 0.4
+    with pytest.raises(AssertionError):
+        assert_outliers_at_mask_edges(bad, g["erp"], tab["mask"], 2e-4)
+    y, x = np.argwhere(near)[0]
+    edge = g["erp"].copy(); edge[0, 0, y, x] += 0.4
+    assert assert_outliers_at_mask_edges(edge, g["erp"], tab["mask"], 2e-4)[0] == 1
+    # at 512x1024 (18 x 256^2) the edge neighbourhoods are 5-pixel-wide curves: 13.5 % of the image, the other 86 % is held to the strict bound
+    tab = co.pers2equi_tables((80, 80), 4, (256, 256), (512, 1024))
+    assert mask_edge_neighbourhood(tab["mask"]).mean() < 0.2

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import golden, rng_uniform, smooth_erp, assert_close_outliers
+from _util import assert_outliers_at_mask_edges, golden, rng_uniform, smooth_erp, assert_close_outliers
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +68,9 @@ def test_pers2equi_golden(name):
     # (DESIGN d2).  Where >= 2 patches overlap the flipped patch carries at most half of the normalised weight, so the change is
     # <= 0.5 * (value range = 1); only nrows = 3 has pixels covered by ONE patch next to uncovered ones (change up to the range).
     assert_close_outliers(erp.cpu().numpy(), g["erp"], tol=2e-4, max_tol=1.0 if "n3" in name else 0.51, frac=1e-4, what=name)
+    # ... and such a pixel may sit only at a patch border of the ORACLE's own validity masks: everywhere else the bound is strict
+    tab = _oracle().pers2equi_tables(fov, nrows, (P, P), (H, W))
+    assert_outliers_at_mask_edges(erp.cpu().numpy(), g["erp"], tab["mask"], 2e-4, what=name)
     planar = t(g["pers"]).permute(0, 4, 1, 2, 3).contiguous()
     erp2 = pers2equi(planar, fov, nrows, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
     assert torch.equal(erp2, erp)
@@ -125,6 +128,9 @@ def test_pers2equi_vs_oracle(cfg):
     ref = co.pers2equi(x, (80, 80), nrows, (P, P), (H, W))
     got = pers2equi(t(x), (80, 80), nrows, (P, P), (H, W), "o").cpu().numpy()
     assert_close_outliers(got, ref, tol=2e-4, max_tol=1.0 if nrows == 3 else 0.51, frac=1e-5, what=str(cfg), ref_nan_max=8 * B * C)
+    if N * H * W <= 18 * 512 * 1024:                               # (the mask tables of 46 patches at 1024x2048 are 3.5 GB)
+        tab = co.pers2equi_tables((80, 80), nrows, (P, P), (H, W))
+        assert_outliers_at_mask_edges(got, ref, tab["mask"], 2e-4, what=str(cfg))
     # consistent patches (what the model produces): strict 1e-3 gate
     erp = smooth_erp(10, B, C, H, W)
     xs, _, _, _ = co.equi2pers(erp, (80, 80), nrows, (P, P))
@@ -268,6 +274,33 @@ def test_high_res_config5_vs_oracle(dtype):
     # (a validity predicate may flip where X, Y sit within round-off of a patch border: the blend of the remaining patches differs
     #  by the disagreement of overlapping patches there — P vs P-1 pixel scale, SURVEY q6 — i.e. a few 1e-3 on values up to 8)
     assert_close_outliers(np.where(ok, e.float().cpu().numpy(), 0.0), np.where(ok, e_ref, 0.0), tol=tol, max_tol=2e-2, frac=1e-5, what="cfg5 pers2equi")
+
+
+def test_high_res_config5_benched_launch_vs_oracle():
+    """The benched BASELINE config-5 launches as bench.py runs them (`configs.cfg5.fp16_b4`): 4 panoramas of 2048x4096, C = 3, fp16, 46 x 512^2
+    patches, planar layout — every plane of equi2pers against the C oracle (12 planes: several plane ranges per tile, gather blocks), and
+    pers2equi (B = 4, C = 1) of the oracle's patches."""
+    _, equi2pers_patches, pers2equi, _, L = _ops()
+    co = _oracle()
+    H, W, P, N, B, C = 2048, 4096, 512, 46, 4, 3
+    x = (smooth_erp(52, 1, 1, H, W) * 8.0)[0, 0]
+    planes = np.stack([np.roll(x, 97 * k, axis=1) * (1.0 - 0.05 * k) for k in range(B * C)]).reshape(B, C, H, W).astype(np.float32)
+    xin = t(planes).half()
+    got = equi2pers_patches(xin, (80, 80), 6, (P, P), layout=L.LAYOUT_BNCHW)
+    assert got.shape == (B, N, C, P, P) and got.dtype == torch.float16
+    xr = xin.float().cpu().numpy()
+    for b in range(B):
+        want = np.transpose(co.equi2pers(xr[b:b + 1], (80, 80), 6, (P, P))[0], (0, 4, 1, 2, 3))      # [1,N,C,P,P]
+        assert_close_outliers(got[b:b + 1].float().cpu().numpy(), want, tol=4e-3, max_tol=2e-2, frac=1e-5, what=f"cfg5 B=4 equi2pers, panorama {b}")
+    pin = got[:, :, :1].contiguous()                                                                  # [B,N,1,P,P] fp16
+    e = pers2equi(pin, (80, 80), 6, (P, P), (H, W), None, layout=L.LAYOUT_BNCHW)
+    assert e.shape == (B, 1, H, W) and e.dtype == torch.float16
+    for b in range(B):
+        e_ref = co.pers2equi(np.transpose(pin[b:b + 1].float().cpu().numpy(), (0, 2, 3, 4, 1)), (80, 80), 6, (P, P), (H, W))
+        ok = np.isfinite(e_ref)
+        assert (~ok).sum() <= 16
+        assert_close_outliers(np.where(ok, e[b:b + 1].float().cpu().numpy(), 0.0), np.where(ok, e_ref, 0.0), tol=4e-3, max_tol=2e-2, frac=1e-5,
+                              what=f"cfg5 B=4 pers2equi, panorama {b}")
 
 
 @pytest.mark.parametrize("cfg", [(8, 3, 512, 1024, 4, 256, "float32"), (2, 3, 512, 1024, 4, 128, "float32"), (1, 2, 1024, 2048, 6, 256, "float32"),

@@ -196,7 +196,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0; g->e2p_ixy = nullptr; g->e2p_ts = 32;
     for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.ord = nullptr; t.nslots = 0; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; t.sum_chunks = 0; }
     for (auto& t : g->e2p_boxes) { t.ent = nullptr; t.fb = nullptr; t.order = nullptr; t.norder = 0; t.nfb = 0; t.max_chunks = 0; t.ok = 0; t.tw = t.th = t.tx = t.ty = 0; }
-    g->p2e_tx = g->p2e_ty = 0;
+    g->p2e_tx = g->p2e_ty = 0; g->pinned = 0;
     g->p2e_bwd_box = nullptr; g->p2e_rden = nullptr; g->p2e_btx = g->p2e_bty = g->p2e_bwd_ok = 0;
     g->p2e_bwd_ids = nullptr; g->p2e_bwd_nsmall = g->p2e_bwd_nbig = 0;
     g->e2p_bwd_box = nullptr; g->e2p_bwd_ids = nullptr; g->e2p_bwd_nsmall = g->e2p_bwd_nbig = g->e2p_gtx = g->e2p_gty = g->e2p_bwd_ok = 0;
@@ -273,15 +273,26 @@ int omni_geometry_lookup(const omni_geometry** out, int nrows, float fov_h, floa
         if (g->device == dev && g->nrows == nrows && g->fov_h == fov_h && g->fov_w == fov_w &&
             g->ph == ph && g->pw == pw && g->H == H && g->W == W) {
             if (i) { g_cache.erase(g_cache.begin() + i); g_cache.insert(g_cache.begin(), g); }
+            // a launch that is being CAPTURED bakes this handle's table pointers into a hipGraph that may be replayed at any later time:
+            // such a handle is never evicted (a replay after >= geom_cache_max other shapes read freed memory)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) g->pinned = 1;
             *out = g; return OMNI_OK;
         }
+    }
+    {   // a new shape under capture cannot be built (allocations, synchronous copies): the caller warms every shape up before capturing
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+            OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_geometry_lookup: first use of a geometry while its stream is being captured (run the shape once before capturing)");
     }
     omni_geometry* g = nullptr;
     int rc = omni_geometry_create(&g, nrows, fov_h, fov_w, ph, pw, H, W, stream);
     if (rc != OMNI_OK) return rc;
     g_cache.insert(g_cache.begin(), g);
     const size_t cap = (size_t)(omni_options().geom_cache_max > 0 ? omni_options().geom_cache_max : 1);
-    while (g_cache.size() > cap) { destroy_drained(g_cache.back()); g_cache.pop_back(); }
+    // evict the least recently used handle that no graph holds (pinned handles stay: the cache may then exceed its cap by their number)
+    for (size_t i = g_cache.size(); i-- > 1 && g_cache.size() > cap;)
+        if (!g_cache[i]->pinned) { destroy_drained(g_cache[i]); g_cache.erase(g_cache.begin() + i); }
     *out = g;
     return OMNI_OK;
 }

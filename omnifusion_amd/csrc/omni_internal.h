@@ -76,6 +76,7 @@ struct PatchTab {
 
 struct omni_geometry {
     int device;
+    int pinned;                    // used by a launch under stream capture: a hipGraph holds its table pointers, the LRU never evicts it
     int nrows, N;
     float fov_h, fov_w;
     int ph, pw, H, W;

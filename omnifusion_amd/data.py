@@ -41,6 +41,9 @@ def preprocess_rgb(frames_u8, size, out=None):
     B, Hs, Ws, _ = f.shape
     if out is None:
         out = torch.empty((B, 3, H, W), dtype=torch.float32, device=f.device)
+    elif (not isinstance(out, torch.Tensor) or out.dtype != torch.float32 or out.device != f.device or tuple(out.shape) != (B, 3, H, W)
+          or not out.is_contiguous()):
+        raise ValueError(f"out must be a contiguous float32 tensor [{B},3,{H},{W}] on {f.device} (the kernel writes through its raw pointer)")
     with torch.cuda.device(f.device):
         _lib.check(_lib.load().omni_preprocess_rgb_u8(_p(f), _p(out), B, Hs, Ws, H, W, _lib.stream_of(f)), "preprocess_rgb")
     return out
@@ -101,27 +104,28 @@ class DeviceFeeder:
         s = self._slots[slot]
         if isinstance(frames, torch.Tensor) and frames.is_pinned():
             # a DataLoader(pin_memory=True) batch: already page-locked, copied to the device straight from where the worker put it
-            if frames.dtype != torch.uint8 or tuple(frames.shape) != tuple(s["dev"].shape):
-                raise ValueError("pinned batches must be uint8 [B,Hs,Ws,3] of one shape")
+            if frames.dtype != torch.uint8 or frames.dim() != 4 or tuple(frames.shape[1:]) != tuple(s["dev"].shape[1:]) or frames.shape[0] > s["dev"].shape[0]:
+                raise ValueError("pinned batches must be uint8 [B' <= B,Hs,Ws,3] of one frame size")
             src = frames
         else:
             a = np.ascontiguousarray(frames.numpy() if isinstance(frames, torch.Tensor) else frames)
             if a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3:
                 raise ValueError("batches must yield uint8 arrays [B,Hs,Ws,3]")
-            if tuple(s["dev"].shape) != a.shape:
-                raise ValueError("all batches of one feeder must have the same shape")
+            if tuple(s["dev"].shape[1:]) != a.shape[1:] or a.shape[0] > s["dev"].shape[0]:
+                raise ValueError("all batches of one feeder must have the same frame size and at most the first batch's length")
             if s["pin"] is None:
-                s["pin"] = torch.empty(a.shape, dtype=torch.uint8).pin_memory()
+                s["pin"] = torch.empty(tuple(s["dev"].shape), dtype=torch.uint8).pin_memory()
             if s["free"] is not None:
                 s["free"].synchronize()                                # (the previous H2D out of this pinned buffer has been consumed)
-            s["pin"].numpy()[...] = a                                  # host memcpy into pinned memory (the worker's hand-over)
-            src = s["pin"]
+            s["pin"].numpy()[:a.shape[0]] = a                          # host memcpy into pinned memory (the worker's hand-over)
+            src = s["pin"][:a.shape[0]]
         if s["free"] is not None:
             self.side.wait_event(s["free"])                            # the consumer's preprocess has read this slot's device frame
         with torch.cuda.stream(self.side):
-            s["dev"].copy_(src, non_blocking=True)                     # async H2D on the side stream
+            s["dev"][:src.shape[0]].copy_(src, non_blocking=True)      # async H2D on the side stream
             s["ready"].record(self.side)
         s["src"] = src                                                 # keep the host buffer alive until the copy has been ordered
+        s["n"] = int(src.shape[0])                                     # (a DataLoader with drop_last=False ends on a shorter batch)
 
     def __iter__(self):
         pending = []
@@ -146,6 +150,8 @@ class DeviceFeeder:
         if self._done[j] is not None:
             cur.wait_event(self._done[j])                              # a consumer on another stream has finished with this buffer
             self._done[j] = None
-        preprocess_rgb(s["dev"], self.size, out=self._outs[j])         # 35 us at 8 x 512x1024; behind the previous forward in stream order
+        n = s.get("n", s["dev"].shape[0])
+        out = self._outs[j][:n]
+        preprocess_rgb(s["dev"][:n], self.size, out=out)               # 35 us at 8 x 512x1024; behind the previous forward in stream order
         ev = torch.cuda.Event(); ev.record(cur); s["free"] = ev        # the slot's device frame may be overwritten after this point
-        return self._outs[j]
+        return out

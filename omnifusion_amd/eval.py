@@ -75,15 +75,20 @@ class DepthMetrics:
         """averages over the meters of every rank of an image-sharded run (omnifusion_amd/dist.py): sums of val*N and of N are
         all-reduced once, at the end — not on the data path"""
         import torch.distributed as dist
-        if self.sum is None:
-            raise RuntimeError("no batch has been evaluated on this rank")
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self.sum is None:
+                # a rank that evaluated nothing (fewer images than ranks) still enters the collective, with zeros — raising here would leave
+                # the other ranks waiting in all_reduce until the RCCL timeout
+                dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and dist.get_backend() == "nccl" else torch.device("cpu")
+                self.sum = torch.zeros(7, dtype=torch.float64, device=dev); self.count = torch.zeros((), dtype=torch.float64, device=dev)
             t = torch.cat([self.sum, self.count.reshape(1)])
             if dist.get_backend() != "nccl":
                 t = t.cpu()
             dist.all_reduce(t)
             t = t.to(self.sum.device)
             return dict(zip(NAMES, (t[:7] / t[7]).cpu().tolist()))
+        if self.sum is None:
+            raise RuntimeError("no batch has been evaluated")
         return self.averages()
 
     def averages(self):

@@ -98,7 +98,9 @@ def test_device_feeder_with_a_consumer_on_other_streams():
         feeder.done_with(rgb, p.input_read)
         pend.append(p)
     got = [p.get() for p in pend]
-    assert len(got) == 9 and all(torch.equal(g, w) for g, w in zip(got, want))
+    torch.cuda.synchronize()
+    diffs = [float((g - w).abs().max()) for g, w in zip(got, want)]
+    assert len(got) == 9 and all(torch.equal(g, w) for g, w in zip(got, want)), f"max |d| per batch: {diffs}"
 
 
 @pytest.mark.parametrize("extra", [[], ["--iterative", "--iter", "2"], ["--depth", "1", "--src-scale", "2"]])

@@ -604,6 +604,47 @@ def test_geometry_cache_is_bounded():
         lib.omni_geometry_cache_clear()
 
 
+def test_captured_geometry_survives_cache_eviction():
+    """a hipGraph bakes the geometry tables' device pointers in; the LRU must never free a handle a captured launch used,
+    however many other shapes come by before the replay."""
+    L, lib = _lib()
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rgb = torch.from_numpy(smooth_erp(41, 1, 3, 64, 128)).to(DEV)
+    ref = net(rgb).clone()
+    lib.omni_geometry_cache_clear()
+    L.set_option("geom_cache_max", 2)
+    try:
+        run = net.graphed(rgb)
+        for k in range(6):                                            # six other shapes: the cap of 2 would have evicted the graph's handles
+            equi2pers_patches(torch.rand((1, 1, 40 + 2 * k, 96), device=DEV), 80, 4, 8)
+        torch.cuda.synchronize()
+        assert torch.equal(run(rgb), ref)
+        assert lib.omni_geometry_cache_size() >= 2
+    finally:
+        L.set_option("geom_cache_max", 16)
+        lib.omni_geometry_cache_clear()
+
+
+def test_model_overflow_flag():
+    """`spherical_fusion.overflowed()` — a checkpoint whose activations leave the fp16 range of the split-half format
+    flips the sticky flag, and the output stays finite (saturation, no inf/NaN)."""
+    spherical_fusion, _, make_state_dict = _nets()
+    sd = make_state_dict(42, 18, False)
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(sd)
+    rgb = torch.from_numpy(smooth_erp(43, 1, 3, 64, 128)).to(DEV)
+    out = net(rgb)
+    assert torch.isfinite(out).all() and not net.overflowed()
+    big = {k: (v * 4e3 if k == "conv1.weight" else v) for k, v in sd.items()}      # stem outputs x 4000: far beyond 65504 after bn1
+    net.load_state_dict(big)
+    out = net(rgb)
+    assert torch.isfinite(out).all()
+    assert net.overflowed() and not net.overflowed()                  # raised once, cleared by the read
+
+
 def test_engine_switches_are_result_neutral():
     """The engine's execution switches: fused up-sampling and passes of a few panoramas through the widest stages change no bit;
     the folded `layer1 + point_feat` and the lone panorama's register-streaming GEMMs change the result by rounding only."""

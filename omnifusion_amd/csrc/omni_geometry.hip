@@ -44,6 +44,7 @@ const OptName kOpts[] = {
     {"e2p_fb_planes", "OMNI_E2P_FB_PLANES", &OmniOptions::e2p_fb_planes, 0},
     {"e2p_fb_pos", "OMNI_E2P_FB_POS", &OmniOptions::e2p_fb_pos, 0},
     {"e2p_region", "OMNI_E2P_REGION", &OmniOptions::e2p_region, 0},
+    {"p2e_band", "OMNI_P2E_BAND", &OmniOptions::p2e_band, 0},
     {"p2e_nbuf", "OMNI_P2E_NBUF", &OmniOptions::p2e_nbuf, 0},
     {"p2e_planes", "OMNI_P2E_PLANES", &OmniOptions::p2e_planes, 0},
     {"geom_cache_max", "OMNI_GEOM_CACHE_MAX", &OmniOptions::geom_cache_max, 16},

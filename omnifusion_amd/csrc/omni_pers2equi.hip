@@ -808,7 +808,7 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
             // XCD the tiles sorted by cost and dealt to the 32 round-robin positions in snake order.  Pure speed: any order is correct.
             std::vector<uint2> he((size_t)ntiles * P2E_MAXC);
             if (hipMemcpy(he.data(), tt.ent, sizeof(uint2) * he.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: copy"); }
-            const int tx = g->p2e_tx, ty = g->p2e_ty, band = omni_xcd_band_rows(ty), nbands = (ty + band - 1) / band;
+            const int tx = g->p2e_tx, ty = g->p2e_ty, band = omni_options().p2e_band > 0 ? omni_options().p2e_band : std::max(1, ty / 8), nbands = (ty + band - 1) / band;   // (one contiguous range of tile rows per XCD: 15.8 us, FETCH 52 MB; 8-row bands 16.0, 4-row 17.2 / 61 MB, 2-row 19.6 / 85 MB)
             auto cost = [&](int wid) { return 2 + (int)(he[(size_t)wid * P2E_MAXC].x >> 26); };
             std::vector<std::pair<long long, int>> bc(nbands);
             for (int b = 0; b < nbands; ++b) {

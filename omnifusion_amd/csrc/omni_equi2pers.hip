@@ -710,6 +710,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
             int gx = xs4 + (qc - rr * bw4) * EPC;
             if (gx >= W) gx -= W;                                                 // the box wraps at the seam
             g[q] = qc < nchunk ? (unsigned)(ymin + rr) * rowb + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;   // past the end: zeros
+            if (OMNI_DBG(a, 64) && (qc & 63) >= 40) g[q] = 0x80000000u;   // (debug bit 64: 3/8 of every piece's lanes read nothing — the volume packed row spans would move)
         }
         if (!OMNI_DBG(a, 2)) {
 #pragma unroll

@@ -34,7 +34,7 @@ struct OmniOptions {
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
     int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 0: fastest per layout (planar: LDS boxes + global atomics; reference layout: ERP-tile gathers, no global atomics) | 1: plain scatter | 2: LDS boxes | 3: gathers
     int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 1: pers2equi backward by global atomics (the round-1 kernel) instead of patch-tile gathers
-    int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging)
+    int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging) | 2: never (not even for ONE plane of a large ERP)
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
     int e2p_store;        // OMNI_E2P_STORE      patch stores of the equi2pers box kernel: 0 plain | 1 non-temporal (default: 106 -> 64-74 us at 16 panoramas, whose 327 MB per launch exceed the 256-MB memory-side cache)
     int e2p_slots;        // OMNI_E2P_SLOTS      wave slots per CU the equi2pers work table plans for (0: 12, what the 12-KiB ring admits)

@@ -743,7 +743,11 @@ int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void
     const bool aligned = ((uintptr_t)pers % 16 == 0) && (!pers2 || (uintptr_t)pers2 % 16 == 0) &&
                          g->pw % EPC == 0 && (g->ph * g->pw) % EPC == 0;
     const long long tensor_bytes = (long long)B * g->N * C * g->ph * g->pw * (long long)sizeof(T);
-    if (a.sX == 1 && tt.ok && aligned && !omni_options().p2e_gather && tensor_bytes < (1ll << 31))   // 32-bit buffer offsets
+    // (ONE plane — a lone panorama's depth map, BASELINE cfg 3 / cfg 5 — has nothing to amortise the boxes over: the launch is bound by the tap
+    //  geometry of its (pixel, patch) pairs, ~100 vector instructions each, and the direct gathers are the shorter program: cfg 3 31.2 vs 33.6 us,
+    //  cfg 5 fp16 108 vs 123 us; at 512x1024 the two are equal)
+    const bool single = planes == 1 && (long long)g->H * g->W >= (1ll << 20) && omni_options().p2e_gather != 2;
+    if (a.sX == 1 && tt.ok && aligned && omni_options().p2e_gather != 1 && !single && tensor_bytes < (1ll << 31))   // 32-bit buffer offsets
         return launch_p2e_lds<T, CONF>(a, g, planes, (size_t)tensor_bytes, stream);
     const int rows4 = (g->H + 3) / 4;
     const int nblocks = omni_xcd_rows_grid(rows4, g->ntx);

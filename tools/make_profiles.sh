@@ -26,6 +26,6 @@ cd $R
   python tools/kbench.py --B 1 --P 512 --H 2048 --W 4096 --nrows 6
   python tools/kbench.py --B 1 --P 512 --H 2048 --W 4096 --nrows 6 --half
   python tools/kbench.py --B 4 --P 512 --H 2048 --W 4096 --nrows 6 --half; } 2>&1 | grep -v amdgpu.ids > $O/${tag}_resample_shapes.txt
-tools/pmc.sh ${tag}r --iters 5 > $O/${tag}_resample_pmc.txt 2>&1
+tools/pmc_resample.sh ${tag}r --iters 5 > $O/${tag}_resample_pmc.txt 2>&1
 tools/pmc_traffic.sh $tag 8 > /dev/null 2>&1
 ls -la $O | grep $tag

@@ -116,3 +116,21 @@ def test_eval_harness_runs_end_to_end(tmp_path, extra):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Avg. Abs. Rel. Error" in r.stdout and "panoramas/s" in r.stdout, r.stdout[-1000:]
     assert any(f.endswith(".ply") for _, _, fs in os.walk(tmp_path) for f in fs)
+
+
+def test_sharded_eval_gives_the_unsharded_averages(tmp_path):
+    """test.py:161 scales by ONE median over the batch; a per-shard median gave a sharded run other averages than the
+    single-GPU one although its depth maps were the same bits.  tools/eval.py now gathers every batch before metering it: the printed
+    averages of a 2-rank run (two gloo ranks sharing this GPU, the hook test_bench_gpu.py uses) equal the 1-rank run's, digit for digit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "tools", "eval.py"), "--batches", "2", "--batch", "4", "--height", "128", "--width", "256",
+            "--ply-every", "0", "--out", str(tmp_path)]
+    def averages(cmd, env):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [ln.strip() for ln in r.stdout.splitlines() if ln.strip().startswith(("Avg.", "Inlier"))]
+    one = averages(base, dict(os.environ))
+    two = averages(base + ["--gpus", "2"], dict(os.environ, OMNI_BENCH_DIST_BACKEND="gloo"))
+    assert len(one) >= 7 and one == two, (one, two)

@@ -15,7 +15,7 @@ There is no dataset in this image (Stanford2D3D is not redistributable and there
 Stanford2D3D-SHAPED synthetic frames — uint8 BGR 512x1024 (or larger with --src-scale) and 16-bit depth — through the same device
 pipeline a real loader would feed (omnifusion_amd/data.py: pinned H2D + INTER_AREA + /255 on a side stream); weights are the
 deterministic random-init generator unless --checkpoint names a reference state_dict.  With --gpus N the batches are sharded by
-image over N ranks (omnifusion_amd/dist.py) and the meters are summed over ranks at the end.
+image over N ranks (omnifusion_amd/dist.py); every rank gathers the batch before metering it (ONE median per batch, as test.py:161).
 """
 import argparse
 import collections
@@ -90,6 +90,11 @@ def main():
         out = out[-1] if args.iterative else out
         if args.ply_every and batch_idx % args.ply_every == 0 and rank == 0:
             write_ply_pointcloud(os.path.join(args.out, f"test_pred_{batch_idx}"), out, rgb)                 # test.py:233-238 (before the in-place scaling)
+        if world > 1:
+            # test.py:161 takes ONE median scaling factor over the whole batch (batch_size = 2): a per-shard median gives other averages than
+            # the single-GPU run.  The shards' depth maps, ground truth and masks are gathered (one all_gather of equal blocks each: teardown
+            # traffic of a batch, 2 MB per panorama) and every rank meters the WHOLE batch — the averages then need no reduction at all.
+            out, depth_gt, mask = (dist.gather_batch(t_.contiguous(), args.batch) for t_ in (out, depth_gt, mask))
         meters.update(out, depth_gt, mask.to(torch.float32))                                                 # test.py:203
 
     inflight = collections.deque()
@@ -105,7 +110,7 @@ def main():
     while inflight:
         finish(*inflight.popleft())
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    avg = meters.averages() if world == 1 else meters.averages_all_ranks()
+    avg = meters.averages()                                                                                  # (sharded runs metered whole batches on every rank, see finish())
     if rank == 0:
         print('  Avg. Abs. Rel. Error: {:.4f}\n  Avg. Sq. Rel. Error: {:.4f}\n  Avg. Lin. RMS Error: {:.4f}\n  Avg. Log RMS Error: {:.4f}\n'
               '  Inlier D1: {:.4f}\n  Inlier D2: {:.4f}\n  Inlier D3: {:.4f}\n'.format(

@@ -31,6 +31,14 @@
 #include "omni_internal.h"
 #include "omni_sh.h"
 
+// Compile-time ablations for tools/convabl.sh (a library variant per value; the product is built with 0): 4 no epilogue | 16, 32, 64 drop the
+// weight-lo / activation-lo / hi.hi product | 128 no operand DMA | 256 no block barrier in the K loop | 512 no fragment reads.  (The debug
+// build's RUN-time bits put branches around the matrix instructions and run 2-5x slower than the product: useless for timing.)
+#ifndef OMNI_CONV_ABL
+#define OMNI_CONV_ABL 0
+#endif
+#define OMNI_ABL(bit) ((OMNI_CONV_ABL & (bit)) != 0)
+
 namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -140,6 +148,30 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
         }
 }
 
+// dst[o .. o+3] = act(v + bias + res): the tail of a split-K sum (v = the partial sums added in slab order), 4 channels at flat index o
+__device__ __forceinline__ void splitk_finish(f4v v, size_t o, const float* __restrict__ bias, const void* __restrict__ res, void* __restrict__ dst,
+                                              int Cout, int act, int dst_sh, int res_f32)
+{
+    if (bias) v += *reinterpret_cast<const f4v*>(bias + (o % Cout));
+    if (res && res_f32) v += *reinterpret_cast<const f4v*>((const float*)res + o);
+    else if (res) {
+        const unsigned char* rp = (const unsigned char*)res + sh_off(o);
+        v += sh_join4(*reinterpret_cast<const h4v*>(rp), *reinterpret_cast<const h4v*>(rp + 64));
+    }
+    if (act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (act == OMNI_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (dst_sh) {
+        h4v hi, lo; sh_split4(v, hi, lo);
+        unsigned char* dp = (unsigned char*)dst + sh_off(o);
+        *reinterpret_cast<h4v*>(dp) = hi; *reinterpret_cast<h4v*>(dp + 64) = lo;
+    } else {
+        *reinterpret_cast<f4v*>((float*)dst + o) = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NST = 3>           // NST stages in flight (the step loop is unrolled by it)
 __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
 {
@@ -221,15 +253,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         constexpr int SLOT = decltype(slot_c)::value;
         unsigned char* sb = lds + SLOT * STAGE + wave * 1024;
         const int so = f_gl * 128;
-        if (f_src) {
+        if (OMNI_ABL(128)) {}                                  // (ablation: no operand traffic)
+        else if (f_src) {
 #pragma unroll
             for (int i = 0; i < APASS; ++i) dma16(rs2, sb + i * (1024 * NW), voff[i], so);
         } else {
 #pragma unroll
             for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * (1024 * NW), voff[i], so);
         }
+        if (!OMNI_ABL(128)) {
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * (1024 * NW), wbase[i], ks * 128);
+            for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * (1024 * NW), wbase[i], ks * 128);
+        }
         if (++f_gl == f_gn) {
             f_gl = 0;
             if (f_src == 0 && G2 > 0) { f_src = 1; f_gn = G2; }
@@ -274,10 +309,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
         else                       wait_vm<0>();
         wait_lds_reads();                                        // my fragment reads of stage ks-1 have returned ...
-        __builtin_amdgcn_s_barrier();                            // ... everybody's pieces have landed; everybody is done reading stage ks-1
+        if (!OMNI_ABL(256)) __builtin_amdgcn_s_barrier();     // ... everybody's pieces have landed; everybody is done reading stage ks-1
         asm volatile("" ::: "memory");
         const unsigned char* sl = lds + SLOT * STAGE;
         h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        if (OMNI_ABL(512)) {                                  // (ablation: no fragment reads)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { ah[kc][i] = (h8v)((_Float16)1.0f); al[kc][i] = ah[kc][i]; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { bh[kc][j] = (h8v)((_Float16)1.0f); bl[kc][j] = bh[kc][j]; }
+            }
+        } else
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
@@ -298,10 +342,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (!OMNI_DBG(a, 64)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
+                    if (!OMNI_ABL(64) && !OMNI_DBG(a, 64)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
                     else { acc[i][j][0] += (float)bh[kc][j][0] * (float)ah[kc][i][0]; }
-                    if (!OMNI_DBG(a, 16)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);   // precision map: weight-lo term
-                    if (!OMNI_DBG(a, 32)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);   // ... activation-lo term
+                    if (!OMNI_ABL(16) && !OMNI_DBG(a, 16)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);   // precision map: weight-lo term
+                    if (!OMNI_ABL(32) && !OMNI_DBG(a, 32)) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);   // ... activation-lo term
                 }
             if (kc == 0) {                                       // stage ks+NST-1, issued under the first half's matrix work
                 __builtin_amdgcn_sched_barrier(0);
@@ -318,7 +362,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
     }(std::make_integer_sequence<int, NST - 1>());
 
-    if (OMNI_DBG(a, 4)) return;
+    if (OMNI_ABL(4) || OMNI_DBG(a, 4)) return;
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -362,23 +406,35 @@ constexpr int HT_W = 32, HPW = HT_W + 2;
 // (cell, 8 channels) loads those once (8 x 16 B), joins hi/lo, evaluates up-sample_sh8_kernel's expression for its 4 pixels and
 // writes the 8 split pieces where the DMA would have put them (out-of-image halo pixels: zeros, the convolution's padding).
 // Same arithmetic, same bits as the two kernels it replaces; one pass over HBM less in each direction for the widest tensors.
-template <int BN, int TH, bool UP2 = false>
+//
+// IW > 0: images narrower than a 32-pixel tile row (layer2-4 and the first decoder stages: 16 x 16, 8 x 8, 4 x 4).  The tile is TH*32
+// CONSECUTIVE pixels of the flattened [M, H, W] index — NSUB bands of SUBROWS whole image rows (8 rows of a 16 x 16 image; two 8 x 8 or
+// eight 4 x 4 images) — each band with its own (SUBROWS+2) x (IW+2) halo in LDS; wave w owns pixels 32w .. 32w+31 of the tile.  Against
+// conv_sh_kernel's im2col tiles (every pixel group fetched once per tap) a K-step brings the weights only: 0.6x the LDS-DMA pieces per
+// matrix instruction at 128 x 128, which is what bounds those layers (tools/convabl.sh: the operand traffic of a layer3 convolution costs
+// as much time as its matrix instructions and overlaps them for a third).  Needs H == W == IW and rows % (TH*32) == 0.
+template <int BN, int TH, bool UP2 = false, int IW = 0>
 __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 {
-    static_assert(!UP2 || TH == 4, "the cell decomposition of the up-sampling halo is written for 4-row tiles");
+    static_assert(!UP2 || (TH == 4 && IW == 0), "the cell decomposition of the up-sampling halo is written for 4-row tiles of wide images");
     constexpr int TN = BN / 32, NW = TH, RPP = 8 * NW;
-    constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
+    constexpr int IWD = IW > 0 ? IW : 1;
+    constexpr int SUBROWS = (TH * 32 / IWD) < IWD ? (TH * 32 / IWD) : IWD, SUBPX = SUBROWS * IWD, NSUB = TH * 32 / SUBPX;
+    constexpr int HPS = (SUBROWS + 2) * (IWD + 2);               // halo pixels of one band
+    static_assert(IW == 0 || (NSUB * SUBPX == TH * 32 && IW * IW % SUBPX == 0), "bands must tile the images");
+    constexpr int HPX = IW > 0 ? NSUB * HPS : (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
     constexpr int APASS = (HA_INSTR + NW - 1) / NW, BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[HA_BYTES + 2 * B_BYTES];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int ntn = a.Cout / BN, tw = a.W / HT_W, th = a.H / TH;
+    const int ntn = a.Cout / BN, tw = IW > 0 ? 1 : a.W / HT_W, th = IW > 0 ? 1 : a.H / TH;
     int bid = a.noxcd ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halos, same A for all tile_n) on one XCD
     const int tile_n = bid % ntn; bid /= ntn;
     const int tx = bid % tw; bid /= tw;
-    const int ty = bid % th; const int m = bid / th;
+    const int ty = bid % th; const int m = bid / th;              // (IW > 0: m = tile index, first pixel m * TH * 32)
     const int y0 = ty * TH, x0 = tx * HT_W, col0 = tile_n * BN;
     const int G1 = a.C1 >> 5, G = (a.C1 + a.C2) >> 5, ksteps = 9 * G;
+    const int pix0 = m * (TH * 32);                               // IW > 0: flattened index of the tile's first pixel
 
     // DMA geometry (as in conv_sh_kernel): lane -> row rl + 32*pass of the region, 16-byte piece pc16/16
     const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
@@ -387,9 +443,17 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
         const int p = rl + RPP * i;
-        const int hy = p / HPW, hx = p - hy * HPW;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        apix[i] = (p < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (m * a.H + iy) * a.W + ix : -1;
+        if constexpr (IW > 0) {
+            const int sb = p / HPS, q = p - sb * HPS, hy = q / (IW + 2), hx = q - hy * (IW + 2);
+            const int first = pix0 + sb * SUBPX;                  // first pixel of the band: image first / IW^2, image row (first % IW^2) / IW
+            const int img = first / (IW * IW), gy0 = (first - img * (IW * IW)) / IW;
+            const int iy = gy0 - 1 + hy, ix = hx - 1;
+            apix[i] = (p < HPX && (unsigned)iy < (unsigned)IW && (unsigned)ix < (unsigned)IW) ? (img * IW + iy) * IW + ix : -1;
+        } else {
+            const int hy = p / HPW, hx = p - hy * HPW;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            apix[i] = (p < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (m * a.H + iy) * a.W + ix : -1;
+        }
     }
     int wbase[BPASS];                                             // weight row (kx, co) = row rl + 32*i of a kernel-row stage
 #pragma unroll
@@ -410,7 +474,8 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
         for (int i = 0; i < APASS; ++i) {
             if (wave + NW * i < HA_INSTR) {
                 const int off = apix[i] >= 0 ? apix[i] * cs4 + soff : (int)0x80000000;
-                if (first) dma16(rs1, sb + i * (1024 * NW), off, 0);
+                if (OMNI_ABL(128)) {}
+                else if (first) dma16(rs1, sb + i * (1024 * NW), off, 0);
                 else       dma16(rs2, sb + i * (1024 * NW), off, 0);
             }
         }
@@ -473,7 +538,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
         const int soff = (ky * 3 * G + g) * 128;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i)
-            if (wave + NW * i < BROWS / 8) dma16(rsw, sb + i * (1024 * NW), wbase[i], soff);
+            if (wave + NW * i < BROWS / 8 && !OMNI_ABL(128)) dma16(rsw, sb + i * (1024 * NW), wbase[i], soff);
     };
 
     // pixel fragment offsets of the nine taps: halo pixel p = (wave+ky)*34 + (lane&31) + kx, row pair d = p >> 1,
@@ -484,7 +549,12 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int p = (wave + ky) * HPW + (lane & 31) + kx, d = p >> 1;
+            int p = (wave + ky) * HPW + (lane & 31) + kx;
+            if constexpr (IW > 0) {
+                const int tp = 32 * wave + (lane & 31), sb = tp / SUBPX, w_ = tp - sb * SUBPX, y = w_ / IW, x = w_ - y * IW;
+                p = sb * HPS + (y + ky) * (IW + 2) + x + kx;
+            }
+            const int d = p >> 1;
             ao[ky * 3 + kx] = d * 256 + ((((p & 1) * 8 + (lane >> 5)) ^ (d & 15)) * 16);
         }
     int fo[4];                                                    // weight fragment offsets (32 consecutive rows)
@@ -506,7 +576,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
         for (int ky = 0; ky < 3; ++ky) {
             wait_vm<0>();                                         // halo (ky == 0) and this kernel row's weights have landed
             wait_lds_reads();                                     // ... and my reads of the other weight buffer have returned
-            __builtin_amdgcn_s_barrier();
+            if (!OMNI_ABL(256)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (ky < 2) issue_b(g, ky + 1, buf ^ 1);              // next weights under this row's matrix work
             else if (g + 1 < G) issue_b(g + 1, 0, buf ^ 1);
@@ -516,16 +586,16 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
                 const int a0 = ao[ky * 3 + kx];
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    const h8v ah = *reinterpret_cast<const h8v*>(lds + (a0 ^ (kc * 32)));
-                    const h8v al = *reinterpret_cast<const h8v*>(lds + (a0 ^ (64 + kc * 32)));
+                    const h8v ah = OMNI_ABL(512) ? (h8v)((_Float16)1.0f) : *reinterpret_cast<const h8v*>(lds + (a0 ^ (kc * 32)));
+                    const h8v al = OMNI_ABL(512) ? (h8v)((_Float16)1.0f) : *reinterpret_cast<const h8v*>(lds + (a0 ^ (64 + kc * 32)));
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const unsigned char* bp = sB + (kx * BN + j * 32) * 128;
-                        const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
-                        const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
-                        if (!OMNI_DBG(a, 16)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
-                        if (!OMNI_DBG(a, 32)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
+                        const h8v bh = OMNI_ABL(512) ? (h8v)((_Float16)1.0f) : *reinterpret_cast<const h8v*>(bp + fo[kc]);
+                        const h8v bl = OMNI_ABL(512) ? (h8v)((_Float16)1.0f) : *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
+                        if (!OMNI_ABL(64)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                        if (!OMNI_ABL(16) && !OMNI_DBG(a, 16)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
+                        if (!OMNI_ABL(32) && !OMNI_DBG(a, 32)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
                     }
                 }
             }
@@ -540,7 +610,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
     }
 
     // ---- epilogue (as conv_sh_kernel): column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
-    const int r = (m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
+    const int r = IW > 0 ? pix0 + 32 * wave + (lane & 31) : (m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
     int c0[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) c0[j] = col0 + j * 32;
@@ -665,24 +735,7 @@ __global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __re
     const size_t o = i * 4;
     f4v v = *reinterpret_cast<const f4v*>(ws + o);
     for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f4v*>(ws + (size_t)s * slab + o);
-    if (bias) v += *reinterpret_cast<const f4v*>(bias + (o % Cout));
-    if (res && res_f32) v += *reinterpret_cast<const f4v*>((const float*)res + o);
-    else if (res) {
-        const unsigned char* rp = (const unsigned char*)res + sh_off(o);
-        v += sh_join4(*reinterpret_cast<const h4v*>(rp), *reinterpret_cast<const h4v*>(rp + 64));
-    }
-    if (act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    else if (act == OMNI_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-    }
-    if (dst_sh) {
-        h4v hi, lo; sh_split4(v, hi, lo);
-        unsigned char* dp = (unsigned char*)dst + sh_off(o);
-        *reinterpret_cast<h4v*>(dp) = hi; *reinterpret_cast<h4v*>(dp + 64) = lo;
-    } else {
-        *reinterpret_cast<f4v*>((float*)dst + o) = v;
-    }
+    splitk_finish(v, o, bias, res, dst, Cout, act, dst_sh, res_f32);
 }
 
 // fp32 NHWC <-> SH (4 channels per thread)
@@ -854,6 +907,16 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
         a.post_rows = (unsigned)(post_elems / (size_t)Cout);
     }
     hipStream_t s = (hipStream_t)stream;
+    // small square images: the halo kernel over bands of whole image rows (IW > 0) where the launch still has a block per CU — 16 x 16 (layer2,
+    // de_conv1_x at >= 4 panoramas: 61.6 -> 49.3 us per layer2 convolution at 8) by default, 8 x 8 as well with conv_img = 2 (layer3: 52.7 -> 50.9)
+    if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && H == W && (W == 16 || (W == 8 && omni_options().conv_img >= 2)) && rows % 128 == 0 &&
+        Cout % 64 == 0 && (rows / 128) * (Cout / 64) >= 256 && omni_options().conv_img > 0 && !omni_options().conv_nohalo) {
+        const int grid = (int)(rows / 128) * (Cout / 64);
+        if (W == 16) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 16>), dim3(grid), dim3(256), 0, s, a);
+        else         hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 8>), dim3(grid), dim3(256), 0, s, a);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
+    }
     if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W % HT_W == 0 && H % 4 == 0 && !omni_options().conv_nohalo) {
         const int th = (H % 8 == 0 && omni_options().conv_halo_th == 8) ? 8 : 4;
         const int grid = M * (H / th) * (W / HT_W);
@@ -915,6 +978,9 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
     ShConvArgs a;
     a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = dst; a.dst_sh = fmt & 1; a.res_f32 = 0;
     a.dbg = 0; a.noxcd = omni_options().conv_noxcd;
+#ifdef OMNI_DEBUG_BUILD
+    a.dbg = omni_debug_bits("OMNI_CONV_DBG");
+#endif
     a.M = M; a.H = H; a.W = W; a.C1 = C; a.C2 = 0; a.Cout = Cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = act;
     a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
     const int grid = M * (H / 4) * (W / HT_W);

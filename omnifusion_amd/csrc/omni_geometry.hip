@@ -26,6 +26,7 @@ const OptName kOpts[] = {
     {"conv_sh_tile", "OMNI_CONV_SH_TILE", &OmniOptions::conv_sh_tile, -1},
     {"conv_nohalo", "OMNI_CONV_NOHALO", &OmniOptions::conv_nohalo, 0},
     {"conv_halo_th", "OMNI_CONV_HALO_TH", &OmniOptions::conv_halo_th, 4},
+    {"conv_img", "OMNI_CONV_IMG", &OmniOptions::conv_img, 1},
     {"conv_nodeep", "OMNI_CONV_NODEEP", &OmniOptions::conv_nodeep, 0},
     {"conv_noxcd", "OMNI_CONV_NOXCD", &OmniOptions::conv_noxcd, 0},
     {"splitk_max", "OMNI_SPLITK_MAX", &OmniOptions::splitk_max, 0},

@@ -220,6 +220,52 @@ def test_conv2d_vs_torch(cfg):
         L.set_option("conv_sh_tile", -1)
 
 
+@pytest.mark.parametrize("cfg", [
+    # M, HW, C1, C2, Cout, res, conv_img
+    (72, 16, 128, 0, 128, True, 1),        # layer2 at four panoramas
+    (40, 16, 64, 64, 256, False, 1),       # two sources (the decoder's concatenation), ragged count of images
+    (144, 8, 64, 0, 256, True, 2),         # 8 x 8 images: two per tile (conv_img = 2)
+])
+def test_conv_small_image_halo_mode_vs_torch(cfg):
+    """3x3 convolutions of 16- and 8-pixel-wide images on the halo kernel (bands of whole image rows, OMNI_CONV_IMG) against a plain PyTorch
+    reference (float64 accumulate) and against the im2col tile kernel it replaces (same operator, another K order)."""
+    L, lib = _lib()
+    M, HW, C1, C2, Cout, use_res, mode = cfg
+    assert (M * HW * HW // 128) * (Cout // 64) >= 256, "the shape must take the new path"
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(M, HW, HW, C1, generator=g)
+    x2 = torch.randn(M, HW, HW, C2, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / np.sqrt((C1 + C2) * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(M, HW, HW, Cout, generator=g) if use_res else None
+    xin = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    ref = F.relu(ref + res.double() if use_res else ref)
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    W16 = split_weights_f16x3(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()).to(DEV)
+    def to_sh(t):
+        if t is None:
+            return None
+        t = t.contiguous().to(DEV); o = torch.empty_like(t)
+        assert lib.omni_sh_from_f32(_p(t), _p(o), ctypes.c_size_t(t.numel()), _stream()) == 0
+        return o
+    S1, S2, SR, B = to_sh(x1), to_sh(x2), to_sh(res), b.to(DEV)
+    outs = {}
+    try:
+        for img in (0, mode):
+            L.set_option("conv_img", img)
+            out = torch.empty((M, HW, HW, Cout), device=DEV)
+            rc = lib.omni_conv2d_sh_f16x3_ws(_p(S1), _p(S2), _p(W16), _p(B), _p(SR), _p(out), 0, M, HW, HW, C1, C2, Cout, 3, 3, 1, 1, 1, 1, None,
+                                             ctypes.c_size_t(0), _stream())
+            assert rc == 0, lib.omni_last_error()
+            outs[img] = out.cpu().double()
+            assert (outs[img] - ref).abs().max().item() < 3e-5, img
+    finally:
+        L.set_option("conv_img", 1)
+    assert not torch.equal(outs[0], outs[mode]), "both settings ran the same kernel"      # (another K order: equal to rounding, not bit for bit)
+    assert (outs[0] - outs[mode]).abs().max().item() < 2e-5
+
+
 def test_sh_elementwise_ops_match_f32():
     """The split-half (SH) variants of stem / maxpool / upsample / broadcast adds equal the fp32 operators up to the
     22-bit split (x = hi + lo*2^-11) of their inputs and outputs."""

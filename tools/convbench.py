@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnifusion_amd import _lib
 from omnifusion_amd.model._engine import split_weights_f16x3
 lib = _lib.load()
+if os.environ.get('LIBPATH'):                     # a variant of the library (tools/convabl.sh)
+    lib = ctypes.CDLL(os.environ['LIBPATH']); lib.omni_last_error.restype = ctypes.c_char_p
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = int(os.environ.get("M", "144"))

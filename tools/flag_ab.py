@@ -1,4 +1,4 @@
-"""A/B of a boolean/int Engine class attribute (FLAG=name, VALS=a,b,..), interleaved in one process: pipelined (depth 3) and plain calls at
+"""A/B of a boolean/int Engine class attribute (FLAG=name, VALS=a,b,..) or of a library option (FLAG=opt:name), interleaved in one process: pipelined (depth 3) and plain calls at
 B panoramas, plus the lone-panorama latency."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,9 @@ ref = None
 acc = {v: ([], [], []) for v in VALS}
 for rnd in range(4):
     for v in VALS:
-        setattr(Engine, FLAG, type(getattr(Engine, FLAG))(v))
+        if FLAG.startswith("opt:"):                                 # a library option (OMNI_* switch) instead of an Engine attribute
+            from omnifusion_amd import _lib; _lib.set_option(FLAG[4:], v)
+        else: setattr(Engine, FLAG, type(getattr(Engine, FLAG))(v))
         o = net(batches[0], confidence=True)
         if ref is None: ref = o.clone()
         same = torch.equal(o, ref)

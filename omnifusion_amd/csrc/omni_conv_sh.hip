@@ -850,7 +850,8 @@ void launch_sh(const ShConvArgs& a, hipStream_t s)
 }  // namespace
 
 // out[M,Ho,Wo,Cout] = act(conv(src1 ++ src2, wt16) + bias + res) with SH activations (see the file header).
-// src1/src2: SH tensors; fmt bit 0: dst is SH (else fp32 NHWC); fmt bit 1: res is fp32 NHWC (else SH); wt16 as for
+// src1/src2: SH tensors; fmt bit 0: dst is SH (else fp32 NHWC); fmt bit 1: res is fp32 NHWC (else SH); fmt bit 2: latency form (few images: the im2col
+// tile kernel also where the halo kernel for small images would be taken; equal to it up to the K summation order); wt16 as for
 // omni_conv2d_nhwc_f16x3_ws.  A plain GEMM is the case H = W = KH = KW = 1 (rows = M).
 // Requirements: C1, C2, Cout multiples of 32, kernels up to 3x3.  split-K as in omni_conv2d_nhwc_f32_ws.
 // `post` (or null): fp32 [post_elems / Cout][Cout] added after the activation, output row index modulo its row count — layer1 + point_feat
@@ -907,10 +908,12 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
         a.post_rows = (unsigned)(post_elems / (size_t)Cout);
     }
     hipStream_t s = (hipStream_t)stream;
-    // small square images: the halo kernel over bands of whole image rows (IW > 0) where the launch still has a block per CU — 16 x 16 (layer2,
-    // de_conv1_x at >= 4 panoramas: 61.6 -> 49.3 us per layer2 convolution at 8) by default, 8 x 8 as well with conv_img = 2 (layer3: 52.7 -> 50.9)
+    // small square images: the halo kernel over bands of whole image rows (IW > 0) — 16 x 16 (layer2, de_conv1_x: 61.6 -> 49.3 us per layer2
+    // convolution at 8 panoramas) by default, 8 x 8 as well with conv_img = 2 (layer3: 52.7 -> 50.9)
+    // (the choice must not depend on the number of images: a panorama's bits are the same in every batch size; a caller that runs ONE panorama,
+    //  where the launch would be a quarter block per CU, asks for the tile kernel with fmt bit 2)
     if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && H == W && (W == 16 || (W == 8 && omni_options().conv_img >= 2)) && rows % 128 == 0 &&
-        Cout % 64 == 0 && (rows / 128) * (Cout / 64) >= 256 && omni_options().conv_img > 0 && !omni_options().conv_nohalo) {
+        Cout % 64 == 0 && !(fmt & 4) && omni_options().conv_img > 0 && !omni_options().conv_nohalo) {
         const int grid = (int)(rows / 128) * (Cout / 64);
         if (W == 16) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 16>), dim3(grid), dim3(256), 0, s, a);
         else         hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 8>), dim3(grid), dim3(256), 0, s, a);

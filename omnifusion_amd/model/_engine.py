@@ -181,7 +181,8 @@ class Engine:
                                                   M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb),
                                                   _p(post), ctypes.c_size_t(post.numel()), self._s)
         elif self.sh:
-            rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), 0 if out_f32 else 1,
+            lat = 4 if (self._bs == 1 and self.latency_plan) else 0     # fmt bit 2: a lone panorama keeps the im2col tiles for 16-wide images
+            rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), (0 if out_f32 else 1) | lat,
                                              M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         else:
             rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), b, _p(res), _p(out), M, H, Wd, C1, C2, Cout,

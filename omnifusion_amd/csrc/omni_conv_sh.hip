@@ -617,6 +617,189 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
     epilogue_row<TN>(acc, acc1, a, (size_t)r, c0, lane, a.dst_sh != 0);
 }
 
+// ------------------------------------------------------------------ de_conv4_0: conv3x3(up2(x)), 32 -> 32 channels, PERSISTENT
+// conv3x3_halo_sh_kernel<32, 4, UP2> spends 12.8 us per block at this shape (144 patches, 128 x 128 outputs: 18 432 blocks) around 0.72 us
+// of matrix work: a chain of dependent round trips — the source pixels of the halo, three kernel-row weight stages each issued one 0.24-us
+// matrix phase ahead of its use, the bias, the stores — that twelve waves per CU do not hide (19 % MFMA-busy).  With ONE input group all
+// nine taps of the weights are 36 KiB: here a block keeps them in LDS for its whole life and walks over tiles, and its eight waves split
+// the work by what they WAIT for (loads and stores retire through one in-order counter: a wave that does both waits for its previous
+// tile's store acknowledges whenever it waits for pixels — measured: 277 us, as slow as the kernel this replaces):
+//   waves 4-7, producers: source pixels global -> registers -> up-sampling arithmetic -> the halo of tile k+1 in LDS (two halo buffers);
+//   waves 0-3, consumers: 54 matrix instructions per wave on the halo of tile k, bias from registers, stores — never a wait on memory.
+// One block barrier per tile hands the buffers over.  Same cells, same K order (ky, kx, k chunk): same bits as the kernel it replaces.
+__global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int ntiles)
+{
+    constexpr int BN = 32, TH = 4, NW = 4, RPP = 8 * NW;
+    constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
+    constexpr int BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128, W_OFF = 2 * HA_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HA_BYTES + 3 * B_BYTES];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool consumer = wave < NW;
+    const int tw = a.W / HT_W, th = a.H / TH, per_img = tw * th;
+    // tiles of this block: XCD x (blocks x mod 8) owns one contiguous range of tiles, its blocks walk it with stride gridDim.x / 8
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+    const int per = (ntiles + 7) >> 3, t_end = min(ntiles, (xcd + 1) * per);
+    int tile = xcd * per + lb;
+    if (tile >= t_end) return;
+    auto origin = [&](int tl, int& m, int& y0, int& x0) { m = tl / per_img; const int r = tl - m * per_img; y0 = (r / tw) * TH; x0 = (r % tw) * HT_W; };
+
+    if (consumer) {
+        // ---- the nine taps' weights, once (three kernel-row stages of the halo kernel's layout, side by side)
+        const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+        const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+        const rsrc_t rsw = make_rsrc(a.wt, (size_t)a.Cout * 9 * 128);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int r = rl + RPP * i, kx = r / BN, co = r - kx * BN;
+                if (wave + NW * i < BROWS / 8) dma16(rsw, lds + W_OFF + ky * B_BYTES + wave * 1024 + i * (1024 * NW), (co * 9 + kx) * 128 + pc16, ky * 3 * 128);
+            }
+        f4v bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + 8 * q + 4 * (lane >> 5)) : (f4v)(0.0f);
+        int ao[9], fo[4];                                        // fragment offsets, as in conv3x3_halo_sh_kernel
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int p = (wave + ky) * HPW + (lane & 31) + kx, d = p >> 1;
+                ao[ky * 3 + kx] = d * 256 + ((((p & 1) * 8 + (lane >> 5)) ^ (d & 15)) * 16);
+            }
+        {
+            const int r = lane & 31, v = r >> 1, h = lane >> 5;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+        }
+        wait_vm<0>();                                             // weights (and bias) have landed
+        __syncthreads();                                          // ... everybody's; the first halo is there
+        for (int it = 0;; ++it) {
+            const unsigned char* ha = lds + (it & 1) * HA_BYTES;
+            // the eight fragments of tap k+1 are read while the six matrix instructions of tap k run
+            f16v acc = (f16v)(0.0f), acc1 = (f16v)(0.0f);
+            h8v fa[2][4], fb[2][4];                               // [buffer][hi k0, hi k1, lo k0, lo k1] of the pixels / of the weights
+            auto read_tap = [&](int tap, int bf) {
+                const int a0 = ao[tap];
+                const unsigned char* bp = lds + W_OFF + (tap / 3) * B_BYTES + ((tap % 3) * BN) * 128;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    fa[bf][k] = *reinterpret_cast<const h8v*>(ha + (a0 ^ (k * 32)));
+                    fb[bf][k] = *reinterpret_cast<const h8v*>(bp + fo[k]);
+                }
+            };
+            read_tap(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int bf = tap & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap + 1 < 9) read_tap(tap + 1, bf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    if (!OMNI_ABL(64)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][kc], acc, 0, 0, 0);
+                    else acc[0] += (float)fb[bf][kc][0] * (float)fa[bf][kc][0] + (float)fb[bf][2 + kc][0] * (float)fa[bf][2 + kc][0];
+                    if (!OMNI_ABL(16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][2 + kc], fa[bf][kc], acc1, 0, 0, 0);
+                    if (!OMNI_ABL(32)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][2 + kc], acc1, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
+                int m, y0, x0; origin(tile, m, y0, x0);
+                const size_t r = (size_t)(m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f4v v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * q + e], 4.8828125e-4f, acc[4 * q + e]);
+                    v += bq[q];
+                    if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                    }
+                    const size_t o = r * BN + 8 * q + 4 * (lane >> 5);
+                    if (OMNI_ABL(2048)) { if (v.x == 12345.678f) act_store4<false>(a.dst, o, v); }
+                    else if (a.dst_sh) act_store4<true>(a.dst, o, v);
+                    else               act_store4<false>(a.dst, o, v);
+                }
+            }
+            tile += nlb;
+            if (tile >= t_end) break;
+            wait_lds_reads();
+            __syncthreads();                                      // this halo buffer is free, the other one is complete
+        }
+        return;
+    }
+
+    // ---- producers: thread (cell, 8 channels) of the 3 x 17 cells of 2 x 2 pixels of a tile's halo (see conv3x3_halo_sh_kernel, UP2)
+    const int ft = t - 64 * NW;
+    const int Hl = a.H >> 1, Wl = a.W >> 1;
+    const int u_c8 = ft & 3, u_cell = ft >> 2, u_ci = u_cell / 17, u_cj = u_cell - u_ci * 17;
+    const bool filler = ft < 51 * 4;
+    auto load_src = [&](int tl, h8v (&ch)[4], h8v (&cl)[4]) {
+        if (!filler) return;
+        int m, y0, x0; origin(tl, m, y0, x0);
+        const int u_k = (y0 >> 1) - 1 + u_ci, u_j = (x0 >> 1) - 1 + u_cj;
+        const int ra = min(max(u_k, 0), Hl - 1), rb = min(max(u_k + 1, 0), Hl - 1), ca = min(max(u_j, 0), Wl - 1), cb = min(max(u_j + 1, 0), Wl - 1);
+        const size_t img = (size_t)m * Hl * Wl;
+        const unsigned char* sp = (const unsigned char*)a.src1 + u_c8 * 16;
+        const size_t so[4] = {(img + (size_t)ra * Wl + ca) * 128, (img + (size_t)ra * Wl + cb) * 128, (img + (size_t)rb * Wl + ca) * 128, (img + (size_t)rb * Wl + cb) * 128};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (OMNI_ABL(4096)) { ch[q] = (h8v)((_Float16)1.0f); cl[q] = ch[q]; }
+            else { ch[q] = *reinterpret_cast<const h8v*>(sp + so[q]); cl[q] = *reinterpret_cast<const h8v*>(sp + so[q] + 64); }
+        }
+    };
+    auto write_halo = [&](int tl, unsigned char* hb, const h8v (&ch)[4], const h8v (&cl)[4]) {
+        if (!filler || OMNI_ABL(1024)) return;
+        int m, y0, x0; origin(tl, m, y0, x0);
+        const int u_k = (y0 >> 1) - 1 + u_ci, u_j = (x0 >> 1) - 1 + u_cj;
+        float v[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[q][e] = fmaf((float)cl[q][e], 4.8828125e-4f, (float)ch[q][e]);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int oy = 2 * u_k + 1 + dy, ox = 2 * u_j + 1 + dx;
+                const float fy = fmaxf(0.5f * ((float)oy + 0.5f) - 0.5f, 0.0f), fx = fmaxf(0.5f * ((float)ox + 0.5f) - 0.5f, 0.0f);
+                const float ly = fy - (float)(int)fy, lx = fx - (float)(int)fx, hy = 1.0f - ly, hx = 1.0f - lx;
+                const bool in = (unsigned)oy < (unsigned)a.H && (unsigned)ox < (unsigned)a.W;
+                h8v oh, ol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float o = hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]);
+                    const _Float16 hh = (fabsf(o) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)o;
+                    oh[e] = in ? hh : (_Float16)0.0f;
+                    ol[e] = in ? (_Float16)((o - (float)hh) * 2048.0f) : (_Float16)0.0f;
+                }
+                const int p = (2 * u_ci + dy) * HPW + 2 * u_cj + dx, d = p >> 1, pc = (p & 1) * 8 + u_c8;
+                *reinterpret_cast<h8v*>(hb + d * 256 + ((pc ^ (d & 15)) * 16)) = oh;
+                *reinterpret_cast<h8v*>(hb + d * 256 + (((pc + 4) ^ (d & 15)) * 16)) = ol;
+            }
+    };
+    // the pixels of tile k+2 are on their way while the halo of tile k+1 is computed (a producer issues no stores: its waits are for loads only)
+    h8v ch[4], cl[4], nh[4], nl[4];
+    load_src(tile, ch, cl);
+    if (tile + nlb < t_end) load_src(tile + nlb, nh, nl);
+    write_halo(tile, lds, ch, cl);
+    __syncthreads();                                              // (the consumers' first barrier)
+    for (int it = 0;; ++it) {
+        const int next = tile + nlb;
+        if (next >= t_end) break;                                 // (the consumers leave at the same point: no barrier after the last tile)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ch[q] = nh[q]; cl[q] = nl[q]; }
+        if (next + nlb < t_end) load_src(next + nlb, nh, nl);
+        write_halo(next, lds + ((it + 1) & 1) * HA_BYTES, ch, cl);
+        __syncthreads();
+        tile = next;
+    }
+}
+
 // ------------------------------------------------------------------ stem: conv 7x7 s2 p3, 3 -> 64, + folded BN + ReLU (f16x3)
 // model/spherical_model.py:254 (conv1, bn1, relu) as an implicit GEMM on the fp16 matrix cores.  K is laid out as
 // (c, ky, kx padded 7 -> 8): one 8-wide MFMA fragment is then 8 CONSECUTIVE input pixels of one (channel, kernel row) — four
@@ -987,6 +1170,11 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
     a.M = M; a.H = H; a.W = W; a.C1 = C; a.C2 = 0; a.Cout = Cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = act;
     a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
     const int grid = M * (H / 4) * (W / HT_W);
+    if (C == 32 && Cout == 32 && omni_options().conv_up2_persist) {    // de_conv4_0: resident weights, one persistent block of 8 waves per CU
+        hipLaunchKernelGGL(conv3x3_up2_g1_kernel, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
+    }
     if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
     else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, true>), dim3(grid * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, a);
     OMNI_HIP(hipGetLastError());

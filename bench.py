@@ -117,18 +117,19 @@ def resample_pair(dev, B, H, W, nrows, P, dtype, reps=20):
             "resample_pair_frac": (b1 + b2) / (t1 + t2) / 1e9 / HBM_PEAK_GBS}
 
 
-def pmc_traffic(B):
-    """HBM bytes of the resample pair (one launch each) from profiles/resample_traffic.json, or (None, why)."""
-    path = os.path.join(ROOT, "profiles", "resample_traffic.json")
+def pmc_traffic(B, name="resample_traffic.json"):
+    """HBM bytes from the PMC counters — of the resample pair (one launch each; tools/pmc_traffic.sh -> profiles/resample_traffic.json) or of
+    one forward of the network (tools/pmc_net.sh -> profiles/network_traffic.json) — if the file was measured on THIS build, else (None, why)."""
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None, "profiles/resample_traffic.json not present"
+        return None, f"profiles/{name} not present"
     with open(path) as fh:
         d = json.load(fh)
     from omnifusion_amd.build import source_hash
     if d.get("build") != source_hash():
-        return None, f"profiles/resample_traffic.json was measured on build {d.get('build')}, this is {source_hash()}"
+        return None, f"profiles/{name} was measured on build {d.get('build')}, this is {source_hash()}"
     if d.get("B") != B:
-        return None, f"profiles/resample_traffic.json was measured at B={d.get('B')}"
+        return None, f"profiles/{name} was measured at B={d.get('B')}"
     return d["traffic_bytes"], d.get("note", "")
 
 
@@ -264,6 +265,7 @@ def main():
     peak = MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS
 
     traffic, traffic_note = pmc_traffic(B)
+    net_traffic, net_traffic_note = pmc_traffic(B, "network_traffic.json")
 
     # ---- the same step fed from HOST memory: decoded uint8 frames in pinned memory -> async H2D + /255 + CHW on a
     # side stream (omnifusion_amd/data.py), double-buffered against the forward.  Reported next to the resident-input `value`,
@@ -383,7 +385,7 @@ def main():
                      "kernel": ("network section (conv_sh_kernel / conv3x3_halo_sh_kernel dominant" if f16x3 else
                                 "network section (conv_igemm_f32_kernel<...> dominant") + "; includes the stem/pool/upsample/LN/"
                                "attention/heads launches)",
-                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": net_traffic, "traffic_note": net_traffic_note,
                      "frac_of_fp16_dense": (3 * tflops if f16x3 else tflops) / MFMA_F16_PEAK_TFLOPS,
                      "frac_of_fp16_dense_algorithmic": tflops / MFMA_F16_PEAK_TFLOPS,
                      "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9,

@@ -837,7 +837,8 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
             if (ROWMAP) e2b_quad_transpose(r, lane);
         };
         auto store = [&](const float (&r)[NPX]) {
-            if (!OMNI_DBG(a, 1)) { if (a.store_mode) E2BStore4<T>::st_nt(dst, r); else E2BStore4<T>::st(dst, r); }
+            if (OMNI_DBG(a, 128)) { if (lane == 0) E2BStore4<T>::st_nt(dst, r); }      // (debug bit 128: the store instruction with ONE active lane — its acknowledge without its bytes)
+            else if (!OMNI_DBG(a, 1)) { if (a.store_mode) E2BStore4<T>::st_nt(dst, r); else E2BStore4<T>::st(dst, r); }
             dst += plane;
             if (++cc == a.C) { cc = 0; dst += bskip; }
         };

@@ -171,7 +171,8 @@ int omni_conv2d_nhwc_f16x3_ws(const float* src1, const float* src2, const void* 
  * halfs then 32 lo halfs (x = hi + lo*2^-11; 128 bytes per group = the footprint of 32 floats).  The producer splits
  * once, consumers stream tiles straight into LDS by LDS-DMA.  src1 and src2 are SH tensors; fmt bit 0: dst is SH
  * (else fp32 NHWC), fmt bit 1: res is fp32 NHWC (else SH), fmt bit 2: latency form — the caller runs so few images (one panorama) that the
- * kernel choice for 16-pixel-wide images should stay with the im2col tiles (results equal up to the K summation order); wt16 as above.
+ * kernel choice for 16-pixel-wide images should stay with the im2col tiles (results equal up to the K summation order) and the epilogue with
+ * the direct 8-byte stores (same bits); wt16 as above.
  * omni_sh_from_f32 / omni_sh_to_f32 convert n elements (n % 32 == 0). */
 int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
                             const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,

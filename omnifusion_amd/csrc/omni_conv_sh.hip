@@ -100,6 +100,7 @@ struct ShConvArgs {
     int res_f32;                             // residual is plain fp32 NHWC instead of SH
     int dbg;                                 // debug build only (OMNI_CONV_DBG): 4 = skip the epilogue
     int noxcd;                               // 1: identity block order (tuning, OMNI_CONV_NOXCD)
+    int epi_lds;                             // 1: SH epilogues through an LDS transposition (16-byte pieces), OMNI_CONV_EPI_LDS
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
     const float* post; unsigned post_rows;   // fp32 [post_rows][Cout] added AFTER the activation, row index modulo post_rows (layer1 + point_feat), or null
 };
@@ -146,6 +147,71 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
             if (dst_sh) act_store4<true>(a.dst, o, v);
             else        act_store4<false>(a.dst, o, v);
         }
+}
+
+// The same epilogue through LDS, for SH outputs (and SH or no residual, no `post`): a wave's NT accumulator tiles of 32 CONSECUTIVE pixel rows
+// r0 .. r0+31 go to a wave-private [32][32 NT + 4] float tile and come back as (pixel, 32-channel group, 8-channel piece) tasks, four
+// consecutive lanes per pixel group: the residual arrives and the result leaves as 16-byte pieces, 64 contiguous bytes per pixel and
+// half (hi | lo) per instruction.  epilogue_row moves 8 bytes per lane, 16 per pixel and instruction — 4.7 M sixteen-byte requests for
+// layer1's 75 MB, which is what its 23-us skeleton is made of.  Same operations on every element in the same order: same bits.
+// `tile` = 32 * (32 NT + 4) floats of LDS owned by this wave (the K loop's buffers, after a block barrier).
+template <int NT>
+__device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r0, int nrows,
+                                                  const int (&c0)[NT], int lane, float* tile)
+{
+    constexpr int PITCH = 32 * NT + 4;
+    {
+        const int px = lane & 31;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4v v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
+                *reinterpret_cast<f4v*>(tile + px * PITCH + 32 * j + 8 * q + 4 * (lane >> 5)) = v;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (wave-private tile: the wave's own writes have landed)
+    constexpr int TASKS = 32 * NT * 4 / 64;                       // (pixel, group, piece) tasks per lane
+    f4v va[TASKS], vb[TASKS]; h8v rh[TASKS], rl[TASKS];
+    size_t off[TASKS]; bool ok[TASKS];
+#pragma unroll
+    for (int k = 0; k < TASKS; ++k) {
+        const int task = k * 64 + lane, px = task / (4 * NT), rem = task - px * (4 * NT), j = rem >> 2, pc = rem & 3;
+        ok[k] = px < nrows;
+        va[k] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc);
+        vb[k] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc + 4);
+        off[k] = ((r0 + px) * a.Cout + c0[j]) * 4 + 16 * pc;     // byte offset of the hi piece (the lo piece: + 64)
+        if (a.bias) { va[k] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc); vb[k] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc + 4); }
+        if (a.res && ok[k]) {
+            rh[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k]);
+            rl[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k] + 64);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TASKS; ++k) {
+        if (!ok[k]) continue;
+        f4v v0 = va[k], v1 = vb[k];
+        if (a.res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] += fmaf((float)rl[k][e], 4.8828125e-4f, (float)rh[k][e]); v1[e] += fmaf((float)rl[k][4 + e], 4.8828125e-4f, (float)rh[k][4 + e]); }
+        }
+        if (a.act == OMNI_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+        } else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = 0.5f * v0[e] * (1.0f + erff(v0[e] * 0.70710678118654752440f)); v1[e] = 0.5f * v1[e] * (1.0f + erff(v1[e] * 0.70710678118654752440f)); }
+        }
+        h4v h0, l0, h1, l1;
+        sh_split4(v0, h0, l0); sh_split4(v1, h1, l1);
+        h8v oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { oh[e] = h0[e]; oh[4 + e] = h1[e]; ol[e] = l0[e]; ol[4 + e] = l1[e]; }
+        *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[k]) = oh;
+        *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[k] + 64) = ol;
+    }
 }
 
 // dst[o .. o+3] = act(v + bias + res): the tail of a split-K sum (v = the partial sums added in slab order), 4 channels at flat index o
@@ -364,6 +430,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
 
     if (OMNI_ABL(4) || OMNI_DBG(a, 4)) return;
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
+    if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {       // split-half output: through LDS, 16-byte pieces (epilogue_tile_lds)
+        static_assert(NW * 32 * (32 * TN + 4) * 4 <= NST * STAGE, "the transposition tiles must fit the K loop's buffers");
+        wait_lds_reads();
+        __syncthreads();                                          // every wave is done with the last stage
+        float* tile = reinterpret_cast<float*>(lds) + wave * (32 * (32 * TN + 4));
+        int c0[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) c0[j] = col0 + wn * (BN / WN) + j * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r0 = row0 + wm * (BM / WM) + i * 32;
+            if (r0 < a.rows) epilogue_tile_lds<TN>(acc[i], acc1[i], a, (size_t)r0, min(32, a.rows - r0), c0, lane, tile);
+            if (i + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the tile is read back before it is written again)
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = row0 + wm * (BM / WM) + i * 32 + (lane & 31);
@@ -614,6 +696,13 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
     int c0[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) c0[j] = col0 + j * 32;
+    if (a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {
+        static_assert(TH * 32 * (32 * TN + 4) * 4 <= (int)sizeof(lds), "the transposition tiles must fit the K loop's buffers");
+        wait_lds_reads();
+        __syncthreads();                                          // every wave is done with the halo and the weights
+        epilogue_tile_lds<TN>(acc, acc1, a, (size_t)(r - (lane & 31)), 32, c0, lane, reinterpret_cast<float*>(lds) + wave * (32 * (32 * TN + 4)));
+        return;
+    }
     epilogue_row<TN>(acc, acc1, a, (size_t)r, c0, lane, a.dst_sh != 0);
 }
 
@@ -632,7 +721,8 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
     constexpr int BN = 32, TH = 4, NW = 4, RPP = 8 * NW;
     constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
     constexpr int BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128, W_OFF = 2 * HA_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HA_BYTES + 3 * B_BYTES];
+    constexpr int E_OFF = 2 * HA_BYTES + 3 * B_BYTES, E_TILE = 32 * 36 * 4;       // a transposition tile per consumer wave (epilogue_tile_lds)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[E_OFF + NW * E_TILE];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -705,7 +795,12 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
+            if (a.dst_sh && a.epi_lds && !OMNI_ABL(2048)) {      // 16-byte pieces through a wave-private LDS tile (302 MB of output: as 8-byte pieces, 19 M requests)
+                int m, y0, x0; origin(tile, m, y0, x0);
+                const f16v ea[1] = {acc}, eb[1] = {acc1};
+                const int c0[1] = {0};
+                epilogue_tile_lds<1>(ea, eb, a, (size_t)(m * a.H + y0 + wave) * a.W + x0, 32, c0, lane, reinterpret_cast<float*>(lds + E_OFF + wave * E_TILE));
+            } else {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
                 int m, y0, x0; origin(tile, m, y0, x0);
                 const size_t r = (size_t)(m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
 #pragma unroll
@@ -1064,7 +1159,7 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: bad shape (kernels up to 3x3)");
     ShConvArgs a;
     a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh; a.res_f32 = (fmt >> 1) & 1;
-    a.dbg = 0; a.noxcd = omni_options().conv_noxcd;
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.epi_lds = omni_options().conv_epi_lds && !(fmt & 4);   // (fmt bit 2, one panorama: the extra barrier and LDS round trip cost more than the wider stores save)
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_CONV_DBG");
 #endif
@@ -1163,7 +1258,7 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv3x3_up2_sh: tensor too large for 32-bit indices");
     ShConvArgs a;
     a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = dst; a.dst_sh = fmt & 1; a.res_f32 = 0;
-    a.dbg = 0; a.noxcd = omni_options().conv_noxcd;
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.epi_lds = omni_options().conv_epi_lds && !(fmt & 4);   // (fmt bit 2, one panorama: the extra barrier and LDS round trip cost more than the wider stores save)
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_CONV_DBG");
 #endif

@@ -289,7 +289,7 @@ class Engine:
         if self.sh and self.fuse_up and Wo % 32 == 0 and Ho % 4 == 0:
             if out is None:
                 out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-            _lib.check(_lib.load().omni_conv3x3_up2_sh_f16x3(_p(x), _p(self.w[key + ".w16"]), _p(self.w[key + ".b"]), _p(out), 0 if out_f32 else 1,
+            _lib.check(_lib.load().omni_conv3x3_up2_sh_f16x3(_p(x), _p(self.w[key + ".w16"]), _p(self.w[key + ".b"]), _p(out), (0 if out_f32 else 1) | (4 if (self._bs == 1 and self.latency_plan) else 0),
                                                              M, H, Wd, C, Cout, act, self._s), "up+conv " + key)
             return out
         return self._conv(self._up(x, M, H, Wd, C, Ho, Wo), key, M, Ho, Wo, C, Cout, 3, 1, 1, act, out_f32=out_f32, out=out)

@@ -155,10 +155,12 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
 // half (hi | lo) per instruction.  epilogue_row moves 8 bytes per lane, 16 per pixel and instruction — 4.7 M sixteen-byte requests for
 // layer1's 75 MB, which is what its 23-us skeleton is made of.  Same operations on every element in the same order: same bits.
 // `tile` = 32 * (32 NT + 4) floats of LDS owned by this wave (the K loop's buffers, after a block barrier).
+// (r1: the pixel row of accumulator column 16 when the 32 columns are two runs of 16 consecutive rows — the stem's 2 x 16 tiles; default r0 + 16)
 template <int NT>
 __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r0, int nrows,
-                                                  const int (&c0)[NT], int lane, float* tile)
+                                                  const int (&c0)[NT], int lane, float* tile, size_t r1 = ~(size_t)0)
 {
+    if (r1 == ~(size_t)0) r1 = r0 + 16;
     constexpr int PITCH = 32 * NT + 4;
     {
         const int px = lane & 31;
@@ -182,7 +184,7 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
         ok[k] = px < nrows;
         va[k] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc);
         vb[k] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc + 4);
-        off[k] = ((r0 + px) * a.Cout + c0[j]) * 4 + 16 * pc;     // byte offset of the hi piece (the lo piece: + 64)
+        off[k] = ((px < 16 ? r0 + px : r1 + (px - 16)) * a.Cout + c0[j]) * 4 + 16 * pc;     // byte offset of the hi piece (the lo piece: + 64)
         if (a.bias) { va[k] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc); vb[k] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc + 4); }
         if (a.res && ok[k]) {
             rh[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k]);
@@ -905,10 +907,11 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
 constexpr int SM_TH = 8, SM_TW = 16, SM_IH = 2 * SM_TH + 5, SM_IW = 2 * SM_TW + 5, SM_IP = 40, SM_G = 6;
 
 __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
-                                                         const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po)
+                                                         const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po, int epi_lds)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char wl[64 * SM_G * 128];
     __shared__ __attribute__((aligned(16))) _Float16 imh[3 * SM_IH * SM_IP], iml[3 * SM_IH * SM_IP];   // the input patch, split ONCE per pixel
+    __shared__ __attribute__((aligned(16))) float etile[4][32 * 36];                                     // a transposition tile per wave (epilogue_tile_lds, one 32-channel group at a time: two blocks per CU stay)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int strips = Po / SM_TH;
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
         rowoff[f] = ((rr / 7) * SM_IH + rr % 7 + 2 * py) * SM_IP + 2 * px;
     }
     ShConvArgs e;
-    e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst; e.post = nullptr; e.post_rows = 1;
+    e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst; e.post = nullptr; e.post_rows = 1; e.epi_lds = epi_lds;
 
     // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
     const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
@@ -999,7 +1002,16 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
             }
         const size_t r = ((size_t)m * Po + oy0 + py) * Po + ox0 + px;
         const int c0[2] = {0, 32};
-        epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
+        if (e.epi_lds) {                                          // 151 MB of output at 8 panoramas: as 16-byte pieces (the wave's two rows of 16 pixels)
+            const size_t ra = ((size_t)m * Po + oy0 + 2 * wave) * Po + ox0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f16v ea[1] = {acc[j]}, eb[1] = {acc1[j]};
+                const int cj[1] = {32 * j};
+                epilogue_tile_lds<1>(ea, eb, e, ra, 32, cj, lane, etile[wave], ra + Po);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
     }
 }
 
@@ -1314,7 +1326,7 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
     const int Po = P / 2;
     const int strips = M * (Po / SM_TH);
     const int split = (strips < 256 && Po % (4 * SM_TW) == 0) ? 4 : (strips < 512 && Po % (2 * SM_TW) == 0) ? 2 : 1;    // same bits either way
-    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po);
+    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

@@ -240,10 +240,13 @@ __device__ __forceinline__ void splitk_finish(f4v v, size_t o, const float* __re
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NST = 3>           // NST stages in flight (the step loop is unrolled by it)
-__global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
+// NL > 0: NL extra LOADER waves issue every LDS-DMA piece of the block and wait for them; the WM x WN matrix waves never touch vector memory
+// inside the K loop (a piece costs the issuing wave 100-185 cycles between matrix instructions: four pieces per K-step against twelve
+// matrix instructions of 32).  Same pieces, same LDS image, same K order: same bits.
+template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>           // NST stages in flight (the step loop is unrolled by it)
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs a)
 {
-    constexpr int NW = WM * WN, RPP = 8 * NW;                   // waves per block; tile rows covered by one DMA pass of the block
+    constexpr int NW = WM * WN, LW = NL > 0 ? NL : NW, RPP = 8 * LW;   // matrix waves; waves that issue DMA; tile rows covered by one DMA pass of the block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
     constexpr int APASS = BM / RPP, BPASS = BN / RPP, LPS = APASS + BPASS;
     static_assert(APASS >= 1 && BPASS >= 1, "a tile side must cover at least one DMA pass");
@@ -253,6 +256,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: LDS-DMA bases stay in scalar registers
     const int wm = wave / WN, wn = wave % WN;
+    const bool loader = NL > 0 && wave >= NW;                   // (wave-uniform)
+    const int iw = NL > 0 ? wave - NW : wave;                   // index among the issuing waves (meaningless in a matrix wave when NL > 0)
     const int ntn = a.Cout / BN;
     // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous range of (tile_m, tile_n) so that the
     // blocks sharing an A row tile (and neighbouring pixels) share one L2
@@ -265,15 +270,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
     // ---- DMA geometry: instruction j of a tile covers LDS row pairs 4j .. 4j+3; wave w issues j = w, w+NW, ...  Lane i
     // owns slot g' = i & 15 of pair d = 4j + (i >> 4), i.e. fetches piece g = g' ^ (d & 15) -> row 2d + (g >> 3), 16-byte
     // piece g & 7.  (d & 15 does not depend on the pass, so the lane's piece is fixed and its row advances by 8 NW per pass.)
-    const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
-    const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+    const int gs = (lane & 15) ^ ((4 * iw + (lane >> 4)) & 15);
+    const int rl = 8 * iw + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
     int pix[APASS];                                              // pixel index of the (possibly padded) window origin
     unsigned vmask[APASS];                                       // bit (ky*KW+kx): tap inside the image
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
         const int r = row0 + rl + RPP * i;
         vmask[i] = 0; pix[i] = 0;
-        if (r < a.rows) {
+        if ((NL == 0 || loader) && r < a.rows) {
             const int hw = a.Ho * a.Wo;
             const int m = r / hw, rem = r - m * hw;
             const int oy = (rem / a.Wo) * a.stride - a.pad, ox = (rem % a.Wo) * a.stride - a.pad;
@@ -319,19 +324,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
     };
     auto issue = [&](int ks, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        unsigned char* sb = lds + SLOT * STAGE + wave * 1024;
+        unsigned char* sb = lds + SLOT * STAGE + iw * 1024;
         const int so = f_gl * 128;
         if (OMNI_ABL(128)) {}                                  // (ablation: no operand traffic)
         else if (f_src) {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) dma16(rs2, sb + i * (1024 * NW), voff[i], so);
+            for (int i = 0; i < APASS; ++i) dma16(rs2, sb + i * (1024 * LW), voff[i], so);
         } else {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * (1024 * NW), voff[i], so);
+            for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * (1024 * LW), voff[i], so);
         }
         if (!OMNI_ABL(128)) {
 #pragma unroll
-            for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * (1024 * NW), wbase[i], ks * 128);
+            for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * (1024 * LW), wbase[i], ks * 128);
         }
         if (++f_gl == f_gn) {
             f_gl = 0;
@@ -365,17 +370,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
         const int per = (ksteps + a.splitk - 1) / a.splitk;
         ks_begin = blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
     }
-    seek(ks_begin);
-    [&]<int... S>(std::integer_sequence<int, S...>) {            // prologue: stages 0 .. NST-2 in flight
-        ((ks_begin + S < ks_end ? issue(ks_begin + S, std::integral_constant<int, S>()) : (void)0), ...);
-    }(std::make_integer_sequence<int, NST - 1>());
+    if (NL == 0 || loader) {
+        seek(ks_begin);
+        [&]<int... S>(std::integer_sequence<int, S...>) {        // prologue: stages 0 .. NST-2 in flight
+            ((ks_begin + S < ks_end ? issue(ks_begin + S, std::integral_constant<int, S>()) : (void)0), ...);
+        }(std::make_integer_sequence<int, NST - 1>());
+    }
+    if (loader) {
+        // ---- a loader wave's K loop: my pieces of stage ks have landed -> barrier (everybody's have; the matrix waves are done with stage
+        // ks-1) -> the pieces of stage ks+NST-1 into the slot stage ks-1 occupied
+        auto lstep = [&](int ks, auto slot_c) {
+            constexpr int SLOT = decltype(slot_c)::value;
+            if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
+            else                       wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ks + NST - 1 < ks_end) issue(ks + NST - 1, std::integral_constant<int, (SLOT + NST - 1) % NST>());
+        };
+        int ks = ks_begin;
+        for (; ks + NST - 1 < ks_end; ks += NST) {
+            [&]<int... S>(std::integer_sequence<int, S...>) { (lstep(ks + S, std::integral_constant<int, S>()), ...); }
+            (std::make_integer_sequence<int, NST>());
+        }
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ((ks + S < ks_end ? lstep(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
+        }(std::make_integer_sequence<int, NST - 1>());
+        if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) __syncthreads();    // (the barrier in front of the LDS epilogue)
+        return;
+    }
 
     auto step = [&](int ks, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         // my pieces of stage ks have landed when at most the NST-2 younger stages are in flight (near the end fewer were issued:
         // a smaller count only waits longer, 0 is always safe)
-        if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
-        else                       wait_vm<0>();
+        if (NL == 0) {
+            if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
+            else                       wait_vm<0>();
+        }
         wait_lds_reads();                                        // my fragment reads of stage ks-1 have returned ...
         if (!OMNI_ABL(256)) __builtin_amdgcn_s_barrier();     // ... everybody's pieces have landed; everybody is done reading stage ks-1
         asm volatile("" ::: "memory");
@@ -417,7 +448,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_sh_kernel(ShConvArgs a)
                 }
             if (kc == 0) {                                       // stage ks+NST-1, issued under the first half's matrix work
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks + NST - 1 < ks_end) issue(ks + NST - 1, std::integral_constant<int, (SLOT + NST - 1) % NST>());
+                if (NL == 0 && ks + NST - 1 < ks_end) issue(ks + NST - 1, std::integral_constant<int, (SLOT + NST - 1) % NST>());
             }
         }
     };
@@ -1157,11 +1188,11 @@ __global__ __launch_bounds__(512) void gemm_rows_sh_kernel(RowsGemmArgs a)
     else          act_store4<false>(a.dst, o, v);
 }
 
-template <int BM, int BN, int WM, int WN, int NST = 3>
+template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>
 void launch_sh(const ShConvArgs& a, hipStream_t s)
 {
     const int grid = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(64 * WM * WN), 0, s, a);
+    hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, NL>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(64 * (WM * WN + NL)), 0, s, a);
 }
 }  // namespace
 
@@ -1263,8 +1294,13 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
     else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s);            // 8 waves
     else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
     else if (tile == 8 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s);   // each wave a 64x64 tile: 0.67 KB of LDS reads per MFMA instead of 1
-    else if (tile == 8 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2>(a, s);
-    else if (tile == 8 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2>(a, s);
+    // (128x128 and 128x64 with four LOADER waves beside the eight matrix waves: layer3 51.3 -> 45.8 us, de_conv0_0 90 -> 79, layer4 43.3 -> 41.3, same bits;
+    //  tile = 9: without them.  256x128 has no registers to spare for a third wave per SIMD.)
+    else if (tile == 8 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2, 3, 4>(a, s);
+    else if (tile == 8 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2, 3, 4>(a, s);
+    else if (tile == 9 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s);
+    else if (tile == 9 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2>(a, s);
+    else if (tile == 9 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2>(a, s);
     else if (tile >= 5 && tile <= 7 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 128, 4, 2>(a, s);
     else if (tile >= 5 && tile <= 7 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 64, 4, 2>(a, s);
     // one round of at most one block per CU (the transformer GEMMs; every deep layer at batch 1): the K loop is pure latency,

@@ -23,7 +23,7 @@ void omni_set_error(const std::string& msg);
 // `omni_set_option()` (include/omnifusion.h) changes one at run time (tests and tools sweep tile shapes with it).  No option
 // changes a result bit except `splitk_max` (it changes the K summation order).  Launch paths read the struct, never getenv().
 struct OmniOptions {
-    int conv_sh_tile;     // OMNI_CONV_SH_TILE   -1 auto (8-wave 256x128 / 128x128 / 128x64 where >= 128 blocks remain) | 0 64x64 | 1 128x64 | 2 128x128 | 3, 4 the 8-wave forms | 5..7 auto without 256x128 (64 / 128 / 256 blocks) | 8 = auto
+    int conv_sh_tile;     // OMNI_CONV_SH_TILE   -1 auto (8-wave 256x128 / 128x128 / 128x64 where >= 128 blocks remain) | 0 64x64 | 1 128x64 | 2 128x128 | 3, 4 the 8-wave forms | 5..7 auto without 256x128 (64 / 128 / 256 blocks) | 8 = auto | 9 = auto without the loader waves
     int conv_nohalo;      // OMNI_CONV_NOHALO    1: never take the halo-reuse 3x3 kernel
     int conv_halo_th;     // OMNI_CONV_HALO_TH   rows per halo block: 4 (default) | 8
     int conv_img;         // OMNI_CONV_IMG       1 (default): 3x3 stride-1 convolutions of 16-pixel-wide images on the halo kernel (bands of whole rows) when the launch has >= 256 blocks and no split-K | 2: 8-wide too | 0: im2col tiles

@@ -202,7 +202,7 @@ def test_conv2d_vs_torch(cfg):
     assert lib.omni_sh_to_f32(_p(S1), _p(back), n32(X1), _stream()) == 0
     assert (back - X1).abs().max().item() <= 2.0 ** -22 * X1.abs().max().item()
     try:
-        for tile in (-1, 0, 1, 2, 3, 4, 5, 7, 8):
+        for tile in (-1, 0, 1, 2, 3, 4, 5, 7, 8, 9):
             L.set_option("conv_sh_tile", tile)
             for S in (1, min(3, ksteps)):
                 for dst_sh in (0, 1):

@@ -32,7 +32,8 @@
 #include "omni_sh.h"
 
 // Compile-time ablations for tools/convabl.sh (a library variant per value; the product is built with 0): 4 no epilogue | 16, 32, 64 drop the
-// weight-lo / activation-lo / hi.hi product | 128 no operand DMA | 256 no block barrier in the K loop | 512 no fragment reads.  (The debug
+// weight-lo / activation-lo / hi.hi product | 128 no operand DMA | 256 no block barrier in the K loop | 512 no fragment reads | conv3x3_up2_g1_kernel: 1024 no
+// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators.  (The debug
 // build's RUN-time bits put branches around the matrix instructions and run 2-5x slower than the product: useless for timing.)
 #ifndef OMNI_CONV_ABL
 #define OMNI_CONV_ABL 0
@@ -213,6 +214,41 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
         for (int e = 0; e < 4; ++e) { oh[e] = h0[e]; oh[4 + e] = h1[e]; ol[e] = l0[e]; ol[4 + e] = l1[e]; }
         *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[k]) = oh;
         *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[k] + 64) = ol;
+    }
+}
+
+// ... and for plain fp32 NHWC outputs without a residual (de_conv4_0 -> the heads): tasks of 4 channels, 8 NT consecutive lanes per pixel, so an
+// instruction writes whole 128-byte pixel groups where the direct form writes 32 bytes of each of 32 pixels.
+template <int NT>
+__device__ __forceinline__ void epilogue_tile_lds_f32(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r0, int nrows,
+                                                      const int (&c0)[NT], int lane, float* tile)
+{
+    constexpr int PITCH = 32 * NT + 4;
+    {
+        const int px = lane & 31;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4v v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
+                *reinterpret_cast<f4v*>(tile + px * PITCH + 32 * j + 8 * q + 4 * (lane >> 5)) = v;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int TASKS = 32 * NT * 8 / 64;
+#pragma unroll
+    for (int k = 0; k < TASKS; ++k) {
+        const int task = k * 64 + lane, px = task / (8 * NT), rem = task - px * (8 * NT), j = rem >> 3, pc = rem & 7;
+        f4v v = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 4 * pc);
+        if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 4 * pc);
+        if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        }
+        if (px < nrows) *reinterpret_cast<f4v*>((float*)a.dst + (r0 + px) * a.Cout + c0[j] + 4 * pc) = v;
     }
 }
 
@@ -801,7 +837,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
         for (int it = 0;; ++it) {
             const unsigned char* ha = lds + (it & 1) * HA_BYTES;
             // the eight fragments of tap k+1 are read while the six matrix instructions of tap k run
-            f16v acc = (f16v)(0.0f), acc1 = (f16v)(0.0f);
+            f16v acc = (f16v)(0.0f), acc1 = (f16v)(0.0f), accx = (f16v)(0.0f), accy = (f16v)(0.0f);
             h8v fa[2][4], fb[2][4];                               // [buffer][hi k0, hi k1, lo k0, lo k1] of the pixels / of the weights
             auto read_tap = [&](int tap, int bf) {
                 const int a0 = ao[tap];
@@ -821,6 +857,15 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
+                    if (OMNI_ABL(8192)) {                         // (ablation: four accumulators instead of two — another summation order)
+                        if (kc == 0) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][kc], acc, 0, 0, 0);
+                                       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][2 + kc], fa[bf][kc], acc1, 0, 0, 0);
+                                       accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][2 + kc], accx, 0, 0, 0); }
+                        else         { accy = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][kc], accy, 0, 0, 0);
+                                       accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][2 + kc], fa[bf][kc], accx, 0, 0, 0);
+                                       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][2 + kc], acc1, 0, 0, 0); }
+                        continue;
+                    }
                     if (!OMNI_ABL(64)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][kc], fa[bf][kc], acc, 0, 0, 0);
                     else acc[0] += (float)fb[bf][kc][0] * (float)fa[bf][kc][0] + (float)fb[bf][2 + kc][0] * (float)fa[bf][2 + kc][0];
                     if (!OMNI_ABL(16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[bf][2 + kc], fa[bf][kc], acc1, 0, 0, 0);
@@ -828,11 +873,17 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (OMNI_ABL(8192)) { acc += accy; acc1 += accx; }
             if (a.dst_sh && a.epi_lds && !OMNI_ABL(2048)) {      // 16-byte pieces through a wave-private LDS tile (302 MB of output: as 8-byte pieces, 19 M requests)
                 int m, y0, x0; origin(tile, m, y0, x0);
                 const f16v ea[1] = {acc}, eb[1] = {acc1};
                 const int c0[1] = {0};
                 epilogue_tile_lds<1>(ea, eb, a, (size_t)(m * a.H + y0 + wave) * a.W + x0, 32, c0, lane, reinterpret_cast<float*>(lds + E_OFF + wave * E_TILE));
+            } else if (!a.dst_sh && a.epi_lds && !OMNI_ABL(2048)) {     // fp32 output (the heads' input): whole 128-byte pixel groups per instruction
+                int m, y0, x0; origin(tile, m, y0, x0);
+                const f16v ea[1] = {acc}, eb[1] = {acc1};
+                const int c0[1] = {0};
+                epilogue_tile_lds_f32<1>(ea, eb, a, (size_t)(m * a.H + y0 + wave) * a.W + x0, 32, c0, lane, reinterpret_cast<float*>(lds + E_OFF + wave * E_TILE));
             } else {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
                 int m, y0, x0; origin(tile, m, y0, x0);
                 const size_t r = (size_t)(m * a.H + y0 + wave) * a.W + x0 + (lane & 31);

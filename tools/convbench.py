@@ -48,7 +48,7 @@ for name, H, W, C1, C2, Cout, k, s, pad, use_res in CFGS:
         lib.omni_sh_from_f32(P(xl), P(xls), ctypes.c_size_t(xl.numel()), S())
     def run():
         if fused_up:
-            rc = lib.omni_conv3x3_up2_sh_f16x3(P(xls), P(w16), P(b), P(out), 1, M, H // 2, W // 2, C1, Cout, 1, S())
+            rc = lib.omni_conv3x3_up2_sh_f16x3(P(xls), P(w16), P(b), P(out), int(os.environ.get("UPFMT", "1")), M, H // 2, W // 2, C1, Cout, 1, S())
             assert rc == 0, lib.omni_last_error()
             return
         if SH:

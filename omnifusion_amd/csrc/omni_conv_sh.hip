@@ -988,63 +988,18 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
 // Output: SH [M, Po, Po, 64].
 constexpr int SM_TH = 8, SM_TW = 16, SM_IH = 2 * SM_TH + 5, SM_IW = 2 * SM_TW + 5, SM_IP = 40, SM_G = 6;
 
-// Eight waves: 0-3 consume (fragment reads, 72 matrix instructions per tile, stores), 4-7 produce (input pixels global -> registers -> hi / lo
-// split -> the NEXT tile's image in LDS, two image buffers) — loads and stores retire through one in-order counter, so a wave that does both
-// waits for its previous stores' acknowledges whenever it waits for pixels (as conv3x3_up2_g1_kernel found); one block barrier per tile.
-__global__ __launch_bounds__(512) void stem_f16x3_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
+__global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
                                                          const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po, int epi_lds)
 {
-    constexpr int IMG = 3 * SM_IH * SM_IP, IPT = (IMG + 255) / 256;
     __shared__ __attribute__((aligned(1024))) unsigned char wl[64 * SM_G * 128];
-    __shared__ __attribute__((aligned(16))) _Float16 imh[2][IMG], iml[2][IMG];                          // the input patch of a tile, split ONCE per pixel; two tiles
-    __shared__ __attribute__((aligned(16))) float etile[4][32 * 36];                                     // a transposition tile per consumer wave (epilogue_tile_lds, one 32-channel group at a time)
+    __shared__ __attribute__((aligned(16))) _Float16 imh[3 * SM_IH * SM_IP], iml[3 * SM_IH * SM_IP];   // the input patch, split ONCE per pixel
+    __shared__ __attribute__((aligned(16))) float etile[4][32 * 36];                                     // a transposition tile per wave (epilogue_tile_lds, one 32-channel group at a time: two blocks per CU stay)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int strips = Po / SM_TH;
     const int m = blockIdx.x / strips, oy0 = (blockIdx.x % strips) * SM_TH;
-    // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
-    const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
 
-    if (wave >= 4) {
-        // ---- producers
-        const int ft = t - 256;
-        float pre[IPT], nxt[IPT];
-        auto fetch = [&](int ox0, float (&v)[IPT]) {
-            const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) {                       // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
-                const int i = ft + 256 * k;
-                const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
-                const int iy = iy0 + r, ix = ix0 + q;
-                v[k] = (i < IMG && q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) ? src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix] : 0.0f;
-            }
-        };
-        auto park = [&](int b, const float (&v)[IPT]) {
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) {
-                const int i = ft + 256 * k;
-                const float x = v[k];
-                const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
-                if (i < IMG) { imh[b][i] = hh; iml[b][i] = (_Float16)((x - (float)hh) * 2048.0f); }
-            }
-        };
-        fetch(ox_first, pre);
-        if (ox_first + SM_TW < ox_last) fetch(ox_first + SM_TW, nxt);
-        park(0, pre);
-        __syncthreads();                                          // (the consumers' first barrier)
-        int b = 0;
-        for (int ox0 = ox_first + SM_TW; ox0 < ox_last; ox0 += SM_TW) {
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) pre[k] = nxt[k];
-            if (ox0 + SM_TW < ox_last) fetch(ox0 + SM_TW, nxt);   // two tiles ahead: in flight while this one is split and parked
-            b ^= 1;
-            park(b, pre);
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---- consumers.  filter bank -> LDS: SM_G regions of 64 rows x 128 B, same pair swizzle as the convolution tiles
+    // filter bank -> LDS: SM_G regions of 64 rows x 128 B, same pair swizzle as the convolution tiles
     {
         const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
         const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
@@ -1072,12 +1027,35 @@ __global__ __launch_bounds__(512) void stem_f16x3_kernel(const float* __restrict
     }
     ShConvArgs e;
     e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst; e.post = nullptr; e.post_rows = 1; e.epi_lds = epi_lds;
-    wait_vm<0>();                                                 // the filter bank has landed
-    __syncthreads();                                              // ... everybody's; the first image is there
-    int b = 0;
+
+    // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
+    const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
+    // the next tile's input pixels travel (global -> registers) under the current tile's matrix work
+    constexpr int IMG = 3 * SM_IH * SM_IP, IPT = (IMG + 255) / 256;
+    float pre[IPT];
+    auto prefetch = [&](int ox0) {
+        const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {                           // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
+            const int i = t + 256 * k;
+            const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
+            const int iy = iy0 + r, ix = ix0 + q;
+            pre[k] = (i < IMG && q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) ? src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix] : 0.0f;
+        }
+    };
+    prefetch(ox_first);
     for (int ox0 = ox_first; ox0 < ox_last; ox0 += SM_TW) {
-        const _Float16* ih = imh[b];
-        const _Float16* il = iml[b];
+        __syncthreads();                                          // the previous tile's fragment reads are done
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int i = t + 256 * k;
+            const float x = pre[k];
+            const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+            if (i < IMG) { imh[i] = hh; iml[i] = (_Float16)((x - (float)hh) * 2048.0f); }
+        }
+        if (ox0 == ox_first) wait_vm<0>();                        // the filter bank has landed
+        __syncthreads();
+        if (ox0 + SM_TW < ox_last) prefetch(ox0 + SM_TW);
         f16v acc[2], acc1[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
@@ -1091,7 +1069,7 @@ __global__ __launch_bounds__(512) void stem_f16x3_kernel(const float* __restrict
                 h8v ah, al;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const h2v xh = *reinterpret_cast<const h2v*>(ih + ro + 2 * u), xl = *reinterpret_cast<const h2v*>(il + ro + 2 * u);
+                    const h2v xh = *reinterpret_cast<const h2v*>(imh + ro + 2 * u), xl = *reinterpret_cast<const h2v*>(iml + ro + 2 * u);
                     ah[2 * u] = xh[0]; ah[2 * u + 1] = xh[1]; al[2 * u] = xl[0]; al[2 * u + 1] = xl[1];
                 }
 #pragma unroll
@@ -1116,10 +1094,6 @@ __global__ __launch_bounds__(512) void stem_f16x3_kernel(const float* __restrict
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
-        if (ox0 + SM_TW >= ox_last) break;                        // (the producers leave at the same point: no barrier after the last tile)
-        wait_lds_reads();
-        __syncthreads();                                          // this image buffer is free, the other one is complete
-        b ^= 1;
     }
 }
 
@@ -1439,7 +1413,7 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
     const int Po = P / 2;
     const int strips = M * (Po / SM_TH);
     const int split = (strips < 256 && Po % (4 * SM_TW) == 0) ? 4 : (strips < 512 && Po % (2 * SM_TW) == 0) ? 2 : 1;    // same bits either way
-    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(512), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
+    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

@@ -217,41 +217,6 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
     }
 }
 
-// ... and for plain fp32 NHWC outputs without a residual (de_conv4_0 -> the heads): tasks of 4 channels, 8 NT consecutive lanes per pixel, so an
-// instruction writes whole 128-byte pixel groups where the direct form writes 32 bytes of each of 32 pixels.
-template <int NT>
-__device__ __forceinline__ void epilogue_tile_lds_f32(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r0, int nrows,
-                                                      const int (&c0)[NT], int lane, float* tile)
-{
-    constexpr int PITCH = 32 * NT + 4;
-    {
-        const int px = lane & 31;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f4v v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
-                *reinterpret_cast<f4v*>(tile + px * PITCH + 32 * j + 8 * q + 4 * (lane >> 5)) = v;
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    constexpr int TASKS = 32 * NT * 8 / 64;
-#pragma unroll
-    for (int k = 0; k < TASKS; ++k) {
-        const int task = k * 64 + lane, px = task / (8 * NT), rem = task - px * (8 * NT), j = rem >> 3, pc = rem & 7;
-        f4v v = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 4 * pc);
-        if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 4 * pc);
-        if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        else if (a.act == OMNI_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-        }
-        if (px < nrows) *reinterpret_cast<f4v*>((float*)a.dst + (r0 + px) * a.Cout + c0[j] + 4 * pc) = v;
-    }
-}
-
 // dst[o .. o+3] = act(v + bias + res): the tail of a split-K sum (v = the partial sums added in slab order), 4 channels at flat index o
 __device__ __forceinline__ void splitk_finish(f4v v, size_t o, const float* __restrict__ bias, const void* __restrict__ res, void* __restrict__ dst,
                                               int Cout, int act, int dst_sh, int res_f32)
@@ -790,8 +755,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
     constexpr int BN = 32, TH = 4, NW = 4, RPP = 8 * NW;
     constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
     constexpr int BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128, W_OFF = 2 * HA_BYTES;
-    constexpr int E_OFF = 2 * HA_BYTES + 3 * B_BYTES, E_TILE = 32 * 36 * 4;       // a transposition tile per consumer wave (epilogue_tile_lds)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[E_OFF + NW * E_TILE];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HA_BYTES + 3 * B_BYTES];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -874,17 +838,8 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
             }
             __builtin_amdgcn_sched_barrier(0);
             if (OMNI_ABL(8192)) { acc += accy; acc1 += accx; }
-            if (a.dst_sh && a.epi_lds && !OMNI_ABL(2048)) {      // 16-byte pieces through a wave-private LDS tile (302 MB of output: as 8-byte pieces, 19 M requests)
-                int m, y0, x0; origin(tile, m, y0, x0);
-                const f16v ea[1] = {acc}, eb[1] = {acc1};
-                const int c0[1] = {0};
-                epilogue_tile_lds<1>(ea, eb, a, (size_t)(m * a.H + y0 + wave) * a.W + x0, 32, c0, lane, reinterpret_cast<float*>(lds + E_OFF + wave * E_TILE));
-            } else if (!a.dst_sh && a.epi_lds && !OMNI_ABL(2048)) {     // fp32 output (the heads' input): whole 128-byte pixel groups per instruction
-                int m, y0, x0; origin(tile, m, y0, x0);
-                const f16v ea[1] = {acc}, eb[1] = {acc1};
-                const int c0[1] = {0};
-                epilogue_tile_lds_f32<1>(ea, eb, a, (size_t)(m * a.H + y0 + wave) * a.W + x0, 32, c0, lane, reinterpret_cast<float*>(lds + E_OFF + wave * E_TILE));
-            } else {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave
+            {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave (through an LDS transposition, split-half or
+                // fp32: 247 | 248 us — the stores are not this kernel's limit, and 18 KB of LDS more per block are felt beside other kernels)
                 int m, y0, x0; origin(tile, m, y0, x0);
                 const size_t r = (size_t)(m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
 #pragma unroll
@@ -1094,6 +1049,142 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
+    }
+}
+
+// ---- the stem with producer / consumer waves (option conv_stem_pc)
+// Eight waves: 0-3 consume (fragment reads, 72 matrix instructions per tile, stores), 4-7 produce (input pixels global -> registers -> hi / lo
+// split -> the NEXT tile's image in LDS, two image buffers) — loads and stores retire through one in-order counter, so a wave that does both
+// waits for its previous stores' acknowledges whenever it waits for pixels (as conv3x3_up2_g1_kernel found); one block barrier per tile.
+__global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
+                                                         const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po, int epi_lds)
+{
+    constexpr int IMG = 3 * SM_IH * SM_IP, IPT = (IMG + 255) / 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char wl[64 * SM_G * 128];
+    __shared__ __attribute__((aligned(16))) _Float16 imh[2][IMG], iml[2][IMG];                          // the input patch of a tile, split ONCE per pixel; two tiles
+    __shared__ __attribute__((aligned(16))) float etile[4][32 * 36];                                     // a transposition tile per consumer wave (epilogue_tile_lds, one 32-channel group at a time)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int strips = Po / SM_TH;
+    const int m = blockIdx.x / strips, oy0 = (blockIdx.x % strips) * SM_TH;
+    // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
+    const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
+
+    if (wave >= 4) {
+        // ---- producers
+        const int ft = t - 256;
+        float pre[IPT], nxt[IPT];
+        auto fetch = [&](int ox0, float (&v)[IPT]) {
+            const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {                       // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
+                const int i = ft + 256 * k;
+                const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
+                const int iy = iy0 + r, ix = ix0 + q;
+                v[k] = (i < IMG && q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) ? src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix] : 0.0f;
+            }
+        };
+        auto park = [&](int b, const float (&v)[IPT]) {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const int i = ft + 256 * k;
+                const float x = v[k];
+                const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+                if (i < IMG) { imh[b][i] = hh; iml[b][i] = (_Float16)((x - (float)hh) * 2048.0f); }
+            }
+        };
+        fetch(ox_first, pre);
+        if (ox_first + SM_TW < ox_last) fetch(ox_first + SM_TW, nxt);
+        park(0, pre);
+        __syncthreads();                                          // (the consumers' first barrier)
+        int b = 0;
+        for (int ox0 = ox_first + SM_TW; ox0 < ox_last; ox0 += SM_TW) {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) pre[k] = nxt[k];
+            if (ox0 + SM_TW < ox_last) fetch(ox0 + SM_TW, nxt);   // two tiles ahead: in flight while this one is split and parked
+            b ^= 1;
+            park(b, pre);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumers.  filter bank -> LDS: SM_G regions of 64 rows x 128 B, same pair swizzle as the convolution tiles
+    {
+        const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+        const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+        const rsrc_t rsw = make_rsrc(wt16, (size_t)64 * SM_G * 128);
+#pragma unroll
+        for (int g = 0; g < SM_G; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                dma16(rsw, wl + g * 8192 + wave * 1024 + i * 4096, ((rl + 32 * i) * SM_G + g) * 128 + pc16, 0);
+    }
+    int fo[4];
+    {
+        const int r = lane & 31, v = r >> 1, h = lane >> 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
+    }
+    // this lane's output pixel inside a tile and its 12 fragment rows: fragment (g, kc) is input row (c, ky) = divmod(4g+2kc+h, 7)
+    const int py = 2 * wave + ((lane & 31) >> 4), px = lane & 15;
+    int rowoff[2 * SM_G];
+#pragma unroll
+    for (int f = 0; f < 2 * SM_G; ++f) {
+        int rr = 2 * f + (lane >> 5);
+        rr = rr < 21 ? rr : 20;                                   // rows 21..23 carry zero weights: any finite data will do
+        rowoff[f] = ((rr / 7) * SM_IH + rr % 7 + 2 * py) * SM_IP + 2 * px;
+    }
+    ShConvArgs e;
+    e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst; e.post = nullptr; e.post_rows = 1; e.epi_lds = epi_lds;
+    wait_vm<0>();                                                 // the filter bank has landed
+    __syncthreads();                                              // ... everybody's; the first image is there
+    int b = 0;
+    for (int ox0 = ox_first; ox0 < ox_last; ox0 += SM_TW) {
+        const _Float16* ih = imh[b];
+        const _Float16* il = iml[b];
+        f16v acc[2], acc1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
+#pragma unroll
+        for (int g = 0; g < SM_G; ++g)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                // 8 consecutive pixels from an even column: four 4-byte reads per half image (every input pixel serves ~28 fragments and
+                // is split once, at load time)
+                const int ro = rowoff[2 * g + kc];
+                h8v ah, al;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const h2v xh = *reinterpret_cast<const h2v*>(ih + ro + 2 * u), xl = *reinterpret_cast<const h2v*>(il + ro + 2 * u);
+                    ah[2 * u] = xh[0]; ah[2 * u + 1] = xh[1]; al[2 * u] = xl[0]; al[2 * u + 1] = xl[1];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char* bp = wl + g * 8192 + j * 4096;
+                    const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
+                    const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
+                }
+            }
+        const size_t r = ((size_t)m * Po + oy0 + py) * Po + ox0 + px;
+        const int c0[2] = {0, 32};
+        if (e.epi_lds) {                                          // 151 MB of output at 8 panoramas: as 16-byte pieces (the wave's two rows of 16 pixels)
+            const size_t ra = ((size_t)m * Po + oy0 + 2 * wave) * Po + ox0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f16v ea[1] = {acc[j]}, eb[1] = {acc1[j]};
+                const int cj[1] = {32 * j};
+                epilogue_tile_lds<1>(ea, eb, e, ra, 32, cj, lane, etile[wave], ra + Po);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
+        if (ox0 + SM_TW >= ox_last) break;                        // (the producers leave at the same point: no barrier after the last tile)
+        wait_lds_reads();
+        __syncthreads();                                          // this image buffer is free, the other one is complete
+        b ^= 1;
     }
 }
 
@@ -1413,7 +1504,8 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
     const int Po = P / 2;
     const int strips = M * (Po / SM_TH);
     const int split = (strips < 256 && Po % (4 * SM_TW) == 0) ? 4 : (strips < 512 && Po % (2 * SM_TW) == 0) ? 2 : 1;    // same bits either way
-    hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
+    if (omni_options().conv_stem_pc) hipLaunchKernelGGL(stem_f16x3_pc_kernel, dim3(strips, split), dim3(512), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
+    else hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

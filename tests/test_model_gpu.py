@@ -720,6 +720,24 @@ def test_engine_switches_are_result_neutral():
             setattr(Engine, k, v)
 
 
+def test_library_kernel_choices_are_result_neutral():
+    """The kernel forms chosen by library options — the stem with producer / consumer waves, split-half epilogues through LDS, loader waves in
+    the tile kernel (conv_sh_tile 8 | 9), the persistent up-sampling convolution — are pure speed: the model's output has the same bits."""
+    L, lib = _lib()
+    spherical_fusion, _, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rgb = torch.rand((4, 3, 64, 128), generator=torch.Generator().manual_seed(5)).to(DEV)
+    ref = net(rgb, confidence=True).clone()
+    for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1)):
+        try:
+            L.set_option(name, value)
+            out = net(rgb, confidence=True)
+            assert torch.equal(out, ref), name
+        finally:
+            L.set_option(name, default)
+
+
 def test_pipelined_forwards_give_the_bits_of_plain_calls():
     """`net.pipelined(depth)`: several complete forwards in flight on several streams (private execution contexts) — same bits
     as one call after the other, also for the iterative model and across a weight reload"""

@@ -249,3 +249,49 @@ extern "C" int omni_debug_victim(int mode, const float* tab, int tabn, const flo
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
+
+// ------------------------------------------------------------------ grid barrier cost ("report the grid-barrier cost you actually see")
+// `blocks` co-resident blocks of `threads` threads cross `iters` device-wide barriers: one agent-scope arrival counter per barrier (relaxed
+// fetch_add by thread 0 behind a block barrier), then thread 0 spins on agent-scope relaxed loads until all have arrived.  With payload != 0
+// every thread first writes 16 bytes with a device-scope store and reads the 16 bytes its neighbour block wrote before the previous barrier
+// (the data hand-off a cooperative transformer layer would make): the exchange, not only the counter, has to cross the XCDs.
+namespace {
+__global__ void grid_barrier_kernel(int* __restrict__ counters, float* __restrict__ buf, int iters, int payload, long long* __restrict__ cycles, float* __restrict__ sink)
+{
+    const int nb = (int)gridDim.x, t = threadIdx.x;
+    float acc = 0.0f;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (payload) {
+            float* mine = buf + ((size_t)(it & 1) * nb + blockIdx.x) * blockDim.x * 4 + t * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) __hip_atomic_store(mine + e, (float)(it + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_fetch_add(counters + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(counters + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nb) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (payload) {
+            const float* theirs = buf + ((size_t)(it & 1) * nb + (blockIdx.x + 1) % nb) * blockDim.x * 4 + t * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += __hip_atomic_load(theirs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const long long t1 = wall_clock64();
+    if (t == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
+    if (acc == -1.0f) sink[0] = acc;
+}
+}  // namespace
+
+// counters: iters ints, ZERO on entry; buf: 2 * blocks * threads * 4 floats; cycles[0] = wall_clock64 ticks (100 MHz) of block 0
+extern "C" int omni_debug_grid_barrier(int* counters, float* buf, int iters, int blocks, int threads, int payload, long long* cycles, float* sink, omni_stream_t stream)
+{
+    if (!counters || !buf || !cycles || !sink || blocks < 1 || blocks > omni_num_cus() * 2 || threads < 64 || threads > 1024) OMNI_FAIL(OMNI_ERR_INVALID, "omni_debug_grid_barrier: bad arguments");
+    hipLaunchKernelGGL(grid_barrier_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, counters, buf, iters, payload, cycles, sink);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

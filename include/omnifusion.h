@@ -187,6 +187,11 @@ int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16
 int omni_gemm_rows_sh_f16x3(const void* x, const void* wt16r, const float* bias, const float* res, void* dst, int fmt,
                             int rows, int K, int N, int act, omni_stream_t stream);
 int omni_gemm_rows_pack(const void* wt16, void* wt16r, int N, int K, omni_stream_t stream);
+/* LayerNorm (model/blocks.py:69,75: nn.LayerNorm(512), eps as given) + the following nn.Linear of one panorama's transformer in ONE launch:
+ * x fp32 [rows <= 32, 512] is normalised by every block itself (the arithmetic of omni_layernorm512_sh), then multiplied as in
+ * omni_gemm_rows_sh_f16x3 (K = 512).  Same bits as the two calls. */
+int omni_gemm_rows_ln_sh_f16x3(const float* x, const float* ln_weight, const float* ln_bias, float eps, const void* wt16r, const float* bias,
+                               const float* res, void* dst, int fmt, int rows, int N, int act, omni_stream_t stream);
 /* F.interpolate(scale_factor 2, bilinear, align_corners=False) + ConvBnReLU (3x3, pad 1) of the decoder, model/spherical_model.py:
  * 279-301, in ONE kernel: the up-sampled tensor never exists.  src SH [M,Hl,Wl,C], dst [M,2Hl,2Wl,Cout] SH (fmt bit 0) or fp32;
  * 2Wl % 32 == 0 and 2Hl % 4 == 0 (else OMNI_ERR_UNSUPPORTED: omni_upsample_bilinear_sh + omni_conv2d_sh_f16x3_ws give the same bits). */

@@ -1304,6 +1304,83 @@ __global__ __launch_bounds__(512) void gemm_rows_sh_kernel(RowsGemmArgs a)
     else          act_store4<false>(a.dst, o, v);
 }
 
+// LayerNorm(512) + the rows GEMM in one launch (K = 512): every block normalises all <= 32 rows itself — one wave per row, layernorm512_kernel's
+// own loads, butterflies and expression, so the split-half values are the ones that kernel would have written — into LDS, where the
+// fragment loads then find them; the block's weights are already travelling (they do not depend on x).  Saves a 3.4-us launch per
+// LayerNorm of a lone panorama's transformer (12 of its 42); same bits as omni_layernorm512_sh + omni_gemm_rows_sh_f16x3.
+__global__ __launch_bounds__(512) void gemm_rows_ln_sh_kernel(RowsGemmArgs a, const float* __restrict__ lg, const float* __restrict__ lb, float eps)
+{
+    constexpr int NWV = 8, KPW = 2, DEPTH = 2, PITCH = 36;
+    __shared__ float red[NWV][32][PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[32 * 2048];           // LayerNorm(x) as split-half rows [32][16 groups][hi32|lo32]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.x * 32, ksteps = 16, ks0 = wave * KPW;
+    const unsigned char* wp = (const unsigned char*)a.wt + ((size_t)blockIdx.x * ksteps + ks0) * 4096 + lane * 16;
+    h8v wh[DEPTH][2], wl[DEPTH][2];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            wh[i][kc] = *reinterpret_cast<const h8v*>(wp + i * 4096 + kc * 1024);
+            wl[i][kc] = *reinterpret_cast<const h8v*>(wp + i * 4096 + 2048 + kc * 1024);
+        }
+    // ---- LayerNorm, one wave per row (rows wave, wave + 8, ...): layernorm512_kernel<true>, writing to LDS
+    for (int row = wave; row < a.rows; row += NWV) {
+        const float* p = (const float*)a.x + (size_t)row * 512;
+        f4v v0 = *reinterpret_cast<const f4v*>(p + lane * 4), v1 = *reinterpret_cast<const f4v*>(p + 256 + lane * 4);
+        float s = (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / 512.0f);
+        v0 -= mean; v1 -= mean;
+        float q = (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + eps);
+        const f4v g0 = *reinterpret_cast<const f4v*>(lg + lane * 4), g1 = *reinterpret_cast<const f4v*>(lg + 256 + lane * 4);
+        const f4v b0 = *reinterpret_cast<const f4v*>(lb + lane * 4), b1 = *reinterpret_cast<const f4v*>(lb + 256 + lane * 4);
+        act_store4<true>(xs, (size_t)row * 512 + lane * 4, v0 * rstd * g0 + b0);
+        act_store4<true>(xs, (size_t)row * 512 + 256 + lane * 4, v1 * rstd * g1 + b1);
+    }
+    __syncthreads();
+    const unsigned char* xp = xs + ((size_t)r * ksteps + ks0) * 128 + h * 32;
+    const bool live = r < a.rows;
+    f16v acc = (f16v)(0.0f), acc1 = (f16v)(0.0f);
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const h8v xh = live ? *reinterpret_cast<const h8v*>(xp + i * 128 + kc * 16) : (h8v)(_Float16)0.0f;
+            const h8v xl = live ? *reinterpret_cast<const h8v*>(xp + i * 128 + 64 + kc * 16) : (h8v)(_Float16)0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i][kc], xh, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i][kc], xh, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i][kc], xl, acc1, 0, 0, 0);
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * q + e], 4.8828125e-4f, acc[4 * q + e]);
+        *reinterpret_cast<f4v*>(&red[wave][r][8 * q + 4 * h]) = v;
+    }
+    __syncthreads();
+    const int tok = t >> 3, c4 = (t & 7) * 4;
+    if (t >= 256 || tok >= a.rows) return;
+    f4v v = *reinterpret_cast<const f4v*>(&red[0][tok][c4]);
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) v += *reinterpret_cast<const f4v*>(&red[w][tok][c4]);
+    const size_t o = (size_t)tok * a.N + col0 + c4;
+    if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + col0 + c4);
+    if (a.res) v += *reinterpret_cast<const f4v*>(a.res + o);
+    if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (a.dst_sh) act_store4<true>(a.dst, o, v);
+    else          act_store4<false>(a.dst, o, v);
+}
+
 template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>
 void launch_sh(const ShConvArgs& a, hipStream_t s)
 {
@@ -1490,6 +1567,20 @@ extern "C" int omni_gemm_rows_sh_f16x3(const void* x, const void* wt16, const fl
     a.x = x; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.rows = rows; a.K = K; a.N = N; a.act = act; a.dst_sh = fmt & 1;
     if (K == 512) hipLaunchKernelGGL(gemm_rows_sh_kernel<2>, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a);
     else          hipLaunchKernelGGL(gemm_rows_sh_kernel<8>, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// LayerNorm over 512 channels (weight lg, bias lb, eps) of x fp32 [rows, 512], then omni_gemm_rows_sh_f16x3 on the result, in one launch
+// (gemm_rows_ln_sh_kernel): the same bits as omni_layernorm512_sh followed by omni_gemm_rows_sh_f16x3.  rows <= 32, K = 512.
+extern "C" int omni_gemm_rows_ln_sh_f16x3(const float* x, const float* lg, const float* lb, float eps, const void* wt16, const float* bias,
+                                          const float* res, void* dst, int fmt, int rows, int N, int act, omni_stream_t stream)
+{
+    if (!x || !lg || !lb || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_ln_sh: null pointer");
+    if (rows <= 0 || rows > 32 || N <= 0 || N % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_ln_sh: 1..32 rows, N a multiple of 32");
+    RowsGemmArgs a;
+    a.x = x; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.rows = rows; a.K = 512; a.N = N; a.act = act; a.dst_sh = fmt & 1;
+    hipLaunchKernelGGL(gemm_rows_ln_sh_kernel, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a, lg, lb, eps);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

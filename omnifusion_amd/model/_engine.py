@@ -8,6 +8,7 @@ allocator), the stream and — once per `load_state_dict` — the constant foldi
 Reference: model/spherical_model.py:238-314 (single pass), model/spherical_model_iterative.py:308-456.
 """
 import ctypes
+import os
 
 import torch
 
@@ -263,6 +264,18 @@ class Engine:
         _lib.check(rc, "gemm " + w16key)
         return out
 
+    fuse_ln = os.environ.get("OMNI_FUSE_LN", "1") != "0"   # a lone panorama: LayerNorm inside the following rows GEMM (one launch instead of two, same bits)
+
+    def _ln_gemm_sh(self, x, lnw, lnb, eps, w16key, bkey, rows, Nout, act=ACT_NONE, out_sh=False):
+        """LayerNorm(512) + GEMM (K = 512) on the fp32 token matrix x [rows, 512]: one launch for a lone panorama, else the two kernels"""
+        if self._bs == 1 and self.latency_plan and self.rows_gemm and self.fuse_ln and rows <= 32:
+            lib = _lib.load()
+            out = torch.empty((rows, Nout), dtype=torch.float32, device=x.device)
+            _lib.check(lib.omni_gemm_rows_ln_sh_f16x3(_p(x), _p(self.w[lnw]), _p(self.w[lnb]), ctypes.c_float(eps), _p(self._rows_weights(w16key, Nout, 512)),
+                                                      _p(self.w[bkey]) if bkey else None, None, _p(out), 1 if out_sh else 0, rows, Nout, act, self._s), "ln+gemm " + w16key)
+            return out
+        return self._gemm_sh(self._ln_sh(x, lnw, lnb, rows, eps), w16key, bkey, rows, 512, Nout, act=act, out_sh=out_sh)
+
     def _ln_sh(self, x, wk, bk, rows, eps):
         y = torch.empty_like(x)
         _lib.check(_lib.load().omni_layernorm512_sh(_p(x), _p(self.w[wk]), _p(self.w[bk]), _p(y), rows, ctypes.c_float(eps), self._s), "layernorm")
@@ -348,13 +361,11 @@ class Engine:
         for i in range(6):
             t = f"t{i}."
             if sh:                                                   # LN / attention emit SH, the GEMMs run f16x3 from it
-                y = self._ln_sh(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)
-                qkv = self._gemm_sh(y, t + "attn.qkv.w16", None, M, 512, 1536)
+                qkv = self._ln_gemm_sh(tok, t + "norm1.weight", t + "norm1.bias", 1e-5, t + "attn.qkv.w16", None, M, 1536)
                 att = new(M, 512)
                 _lib.check(lib.omni_attention_qkv_sh(_p(qkv), _p(att), bs, N, self._s), "attention")
                 tok = self._gemm_sh(att, t + "attn.proj.w16", t + "attn.proj.bias", M, 512, 512, res=tok)
-                y = self._ln_sh(tok, t + "norm2.weight", t + "norm2.bias", M, 1e-5)
-                h = self._gemm_sh(y, t + "mlp.fc1.w16", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU, out_sh=True)
+                h = self._ln_gemm_sh(tok, t + "norm2.weight", t + "norm2.bias", 1e-5, t + "mlp.fc1.w16", t + "mlp.fc1.bias", M, 2048, act=ACT_GELU, out_sh=True)
                 tok = self._gemm_sh(h, t + "mlp.fc2.w16", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
                 continue
             y = self._ln(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)

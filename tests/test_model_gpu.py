@@ -701,10 +701,10 @@ def test_engine_switches_are_result_neutral():
     net_it.load_state_dict(make_state_dict(42, 18, True))
     rgb = torch.rand((3, 3, 128, 256), generator=torch.Generator().manual_seed(31)).to(DEV)
     one = rgb[:1].contiguous()
-    defaults = {k: getattr(Engine, k) for k in ("fuse_up", "tail_chunk", "front_chunk", "fold_point_feat", "rows_gemm")}
+    defaults = {k: getattr(Engine, k) for k in ("fuse_up", "tail_chunk", "front_chunk", "fold_point_feat", "rows_gemm", "fuse_ln")}
     ref, ref1, ref_it = net(rgb, confidence=True).clone(), net(one, confidence=True).clone(), net_it(rgb, 2)[-1].clone()
     try:
-        for name, value, exact in (("fuse_up", False, True), ("tail_chunk", 1, True), ("tail_chunk", 2, True), ("front_chunk", 1, True),
+        for name, value, exact in (("fuse_ln", False, True), ("fuse_up", False, True), ("tail_chunk", 1, True), ("tail_chunk", 2, True), ("front_chunk", 1, True),
                                    ("fold_point_feat", False, False), ("rows_gemm", False, False)):
             setattr(Engine, name, value)
             out, out1, out_it = net(rgb, confidence=True), net(one, confidence=True), net_it(rgb, 2)[-1]

@@ -87,6 +87,15 @@ def build(force=False, verbose=False, debug=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
+    if not debug:
+        # the ISA guard (omnifusion_amd/isa.py): no packed-fp32 arithmetic anywhere, no scratch in the kernels that count their own
+        # s_waitcnt vmcnt(N).  A violation fails the build BEFORE a library exists that could be loaded.
+        from . import isa
+        bad = isa.check(objs)
+        if bad:
+            if os.path.exists(lib):
+                os.remove(lib)
+            raise RuntimeError("ISA check failed:\n  " + "\n  ".join(bad))
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib
 

@@ -1177,16 +1177,27 @@ namespace {
 struct E2PWork { uint4* dev = nullptr; int nblocks = 0; };
 
 template <int E>
-int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWork& out)
+int e2p_work_table(const omni_geometry* gc, int planes, int nbmax, hipStream_t stream, E2PWork& out)
 {
     omni_geometry* g = const_cast<omni_geometry*>(gc);             // (the cache is a mutable part of the handle)
     auto& tt = g->e2p_boxes[E];
     const OmniOptions& o = omni_options();
     const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : 12, split = o.e2p_split > 0 ? o.e2p_split : 3,
               fbp = o.e2p_fb_planes > 0 && o.e2p_fb_planes < 90 ? o.e2p_fb_planes : std::min(tt.norder < slots_cu * omni_num_cus() ? 6 : 12, planes);   // (shorter where the launch is under one round: P = 128)
-    const long long key = ((long long)planes << 32) | ((long long)(C & 0xff) << 24) | ((long long)(slots_cu & 0xff) << 16) | ((long long)(split & 0xff) << 8) | (long long)((fbp & 0xf) << 4 | (nbmax & 0xf)) | ((long long)(o.e2p_fb_planes >= 98 ? o.e2p_fb_planes - 97 : 0) << 52) | ((long long)(o.e2p_fb_pos & 3) << 54) | ((long long)((o.e2p_full + 1) & 0xff) << 56);
+    // key = everything the table depends on: the plane count and the option set (NOT the channel count: the table holds plane ranges, the
+    // kernel splits a plane index into (batch item, channel) itself — B * 3 and 3 B * 1 planes share one table).  Every field whole (ADVICE r3:
+    // `e2p_fb_pos & 3` made 4 an alias of 0).
+    const long long key = ((long long)planes << 40) | ((long long)(slots_cu & 0xff) << 32) | ((long long)(split & 0xff) << 24) | ((long long)(fbp & 0xff) << 16) |
+                          ((long long)(nbmax & 0xf) << 12) | ((long long)(o.e2p_fb_planes >= 98 ? o.e2p_fb_planes - 97 : 0) << 10) | ((long long)(o.e2p_fb_pos & 7) << 7) |
+                          ((long long)((o.e2p_full + 1) & 0x7f));
     std::lock_guard<std::mutex> lk(g->work_mu);
     for (auto& w : tt.work) if (w.key == key) { out.dev = w.dev; out.nblocks = w.nblocks; return OMNI_OK; }
+    {   // a new plane count under capture cannot be served (an allocation and a synchronous copy would invalidate the capture): like a new
+        // geometry, it must have been run once before the capture starts
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+            OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: first use of a plane count (B * C) on this geometry while its stream is being captured (run the shape once before capturing)");
+    }
     const int slots_xcd = slots_cu * (omni_num_cus() / 8);
     std::vector<std::vector<uint4>> col(8);
     auto seg = [&](int wid, bool fb, int p0, int np) { return make_uint4((unsigned)wid | (fb ? 0x80000000u : 0u), (unsigned)p0 | ((unsigned)np << 16), tt.h_ent[wid].x, tt.h_ent[wid].y); };
@@ -1230,7 +1241,10 @@ int e2p_work_table(const omni_geometry* gc, int planes, int C, int nbmax, E2PWor
     uint4* dev = nullptr;
     OMNI_HIP(hipMalloc((void**)&dev, sizeof(uint4) * tab.size()));
     if (hipMemcpy(dev, tab.data(), sizeof(uint4) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); OMNI_FAIL(OMNI_ERR_HIP, "omni_equi2pers: work table upload"); }
-    if (tt.work.size() >= 16) { (void)hipDeviceSynchronize(); (void)hipFree(tt.work.front().dev); tt.work.erase(tt.work.begin()); }   // (tuning sweeps only: 16 plane counts x option sets)
+    if (tt.work.size() >= 256) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: more than 256 distinct plane counts / option sets on one geometry handle (omni_geometry_cache_clear() drops them)");
+    // a table lives as long as its geometry handle (omni_geometry.hip frees them with it; a handle a hipGraph holds is pinned and never
+    // destroyed): a launch in flight on another stream, or a captured graph, may hold the pointer — never freed here (the FIFO
+    // that was here freed tables under running kernels).  A table is 16 B per block, ~100 KB; one per plane count seen.
     tt.work.push_back({key, dev, (int)tab.size()});
     out.dev = dev; out.nblocks = (int)tab.size();
     return OMNI_OK;
@@ -1242,7 +1256,7 @@ int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t
     constexpr int E = sizeof(T) == 2 ? 1 : 0;
     const auto& tt = g->e2p_boxes[E];
     E2PWork wk;
-    int rc = e2p_work_table<E>(g, B * C, C, NBMAX, wk);
+    int rc = e2p_work_table<E>(g, B * C, NBMAX, stream, wk);
     if (rc != OMNI_OK) return rc;
     const int njmax = (tt.max_chunks + 63) / 64;
     const size_t lds = (size_t)(njmax > E2B_RING_KB ? njmax : E2B_RING_KB) * 1024;

@@ -21,7 +21,9 @@ void omni_set_error(const std::string& msg);
 // ---------------------------------------------------------------- tuning options
 // Read ONCE from the environment (OMNI_* variables, DESIGN.md "Environment switches") the first time the library needs them;
 // `omni_set_option()` (include/omnifusion.h) changes one at run time (tests and tools sweep tile shapes with it).  No option
-// changes a result bit except `splitk_max` (it changes the K summation order).  Launch paths read the struct, never getenv().
+// changes a result bit except the three that change the K summation ORDER of a convolution: `splitk_max`, `conv_img` (16-wide images on
+// the halo kernel: K runs (tap, group) per channel group instead of im2col order) and the latency form a lone panorama selects (fmt bit 2
+// of omni_conv2d_sh_f16x3_ws) — results then agree to ~2e-5, not bit for bit (tests assert exactly that).  Launch paths read the struct, never getenv().
 struct OmniOptions {
     int conv_sh_tile;     // OMNI_CONV_SH_TILE   -1 auto (8-wave 256x128 / 128x128 / 128x64 where >= 128 blocks remain) | 0 64x64 | 1 128x64 | 2 128x128 | 3, 4 the 8-wave forms | 5..7 auto without 256x128 (64 / 128 / 256 blocks) | 8 = auto | 9 = auto without the loader waves
     int conv_nohalo;      // OMNI_CONV_NOHALO    1: never take the halo-reuse 3x3 kernel
@@ -48,7 +50,7 @@ struct OmniOptions {
     int e2p_region;       // OMNI_E2P_REGION     which tiles share an XCD: 0 ERP sectors (4 longitudes x 2 hemispheres) | 1 eight latitude bands of equal cost
     int e2p_fb_pos;       // OMNI_E2P_FB_POS     where the gather blocks go: 0 / 3 first | 1 behind the whole tiles | 2 behind the first plane range of the cut tiles | 4 last
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
-    int p2e_band;         // OMNI_P2E_BAND       tile rows per XCD band of the pers2equi block order (0: rows / 16, at most 8)
+    int p2e_band;         // OMNI_P2E_BAND       tile rows per XCD band of the pers2equi block order (0: max(1, tile rows / 8) — ONE contiguous range of tile rows per XCD)
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16

@@ -713,12 +713,15 @@ int launch_p2e_lds(const P2EArgs& a, const omni_geometry* g, int planes, size_t 
     // planes per wave: 8, 4, 2 or 1 (the tap geometry is evaluated once per wave and patch and amortised over them); the groups go to
     // blockIdx.y.  A plane count that is not a multiple of 8 runs as up to four launches over consecutive plane ranges (7 = 4 + 2 + 1)
     // instead of falling to one plane per wave, where the geometry is as much work as the blend.
-    const int cap = omni_options().p2e_planes > 0 ? omni_options().p2e_planes : (CONF ? 4 : 8);   // (CONF, 8 planes: 2 x 16 accumulators spill at 128 VGPRs)
+    // (CONF, 8 planes: 2 x 16 accumulators spill at 128 VGPRs, and a scratch access inside the DMA pipeline would shift every hand-counted
+    //  s_waitcnt vmcnt(N) — that form is not instantiated at all; omnifusion_amd/isa.py checks that no counted-wait kernel has scratch)
+    constexpr int CAPMAX = CONF ? 4 : 8;
+    const int cap = std::min(CAPMAX, omni_options().p2e_planes > 0 ? omni_options().p2e_planes : CAPMAX);
     int p = 0;
     while (p < planes) {
         const int left = planes - p;
-        int rc;
-        if (left >= 8 && cap >= 8)      { const int n = left / 8 * 8; rc = launch_p2e_lds_pl<T, 8, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
+        int rc = OMNI_OK;
+        if (left >= 8 && cap >= 8)      { const int n = left / 8 * 8; if constexpr (!CONF) rc = launch_p2e_lds_pl<T, 8, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
         else if (left >= 4 && cap >= 4) { const int n = left / 4 * 4; rc = launch_p2e_lds_pl<T, 4, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
         else if (left >= 2 && cap >= 2) { const int n = left / 2 * 2; rc = launch_p2e_lds_pl<T, 2, CONF>(a, g, p, n, tensor_bytes, stream); p += n; }
         else                            { rc = launch_p2e_lds_pl<T, 1, CONF>(a, g, p, left, tensor_bytes, stream); p += left; }
@@ -855,6 +858,7 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
             if (hipMalloc((void**)&tt.ord, sizeof(uint2) * ord.size()) != hipSuccess ||
                 hipMemcpy(tt.ord, ord.data(), sizeof(uint2) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: order table"); }
         }
+        (void)hipFree(tt.ent); tt.ent = nullptr;                     // the kernels read only the ordered table (tt.ord)
         if (omni_options().e2p_verbose)
             fprintf(stderr, "[omni] pers2equi %dx%d <- %d patches %dx%d, %d-byte elements: largest tap box %d chunks, <= %d patches and <= %d chunks per %dx%d tile -> %s\n",
                     g->H, g->W, g->N, g->ph, g->pw, 16 / epc, hs[0], hs[1], hs[2], P2E_TH, P2E_TW, tt.ok ? "LDS path" : "gather path");

@@ -190,7 +190,7 @@ class Engine:
                                              k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "conv2d " + key)
         if late_post is not None:
-            _lib.check((lib.omni_add_period_sh if self.sh else lib.omni_add_period_f32)(
+            _lib.check((lib.omni_add_period_f32 if (out_f32 or not self.sh) else lib.omni_add_period_sh)(   # an fp32 NHWC output is never split-half
                 _p(out), _p(late_post), ctypes.c_size_t(out.numel()), ctypes.c_size_t(late_post.numel()), self._s), "add post " + key)
         return out
 

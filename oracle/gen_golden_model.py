@@ -74,5 +74,32 @@ def main():
     _save("G7b_model_iterative_n6", rgb=rgb6, it0=o6[0].numpy(), it1=o6[1].numpy())
 
 
+def main_presets():
+    """G6c / G7c (round 4): the two `nrows` presets the full network had no reference-backed check at — nrows 3 (10 patches, the
+    preset whose pers2equi centres differ from equi2pers's, q7, and which leaves ERP pixels uncovered) and nrows 5 (26 patches), equi2pers_v3.py:40-47.
+    Single pass with and without confidence, and the 2-iteration iterative model; same weight generator, new files only."""
+    ref = load_reference()
+    for nrows, N, seed in ((3, 10, 602), (5, 26, 603)):
+        torch.manual_seed(0)
+        rgb = smooth_erp(seed, 2, 3, 64, 128, k=9, passes=1)
+        x = torch.from_numpy(rgb)
+        net = ref.spherical_fusion(nrows=nrows, npatches=N, patch_size=(128, 128), fov=(80, 80))
+        net.load_state_dict(make_state_dict(42, N, False))
+        net.eval()
+        with scratch_cwd(), torch.no_grad():
+            oc = net(x, confidence=True)
+        with scratch_cwd(), torch.no_grad():
+            on = net(x, confidence=False)
+        neti = ref.spherical_fusion_iterative(nrows=nrows, npatches=N, patch_size=(128, 128), fov=(80, 80))
+        neti.load_state_dict(make_state_dict(42, N, True))
+        neti.eval()
+        with scratch_cwd(), torch.no_grad():
+            oi = neti(x[:1], 2, confidence=False)
+        _save(f"G6c_model_n{nrows}", rgb=rgb, depth_conf=oc.numpy(), depth_noconf=on.numpy(), it0=oi[0].numpy(), it1=oi[1].numpy())
+
+
 if __name__ == "__main__":
-    main()
+    if "--presets" in sys.argv:
+        main_presets()
+    else:
+        main()

@@ -92,3 +92,13 @@ def assert_outliers_at_mask_edges(got, want, mask, tol, what=""):
     stray = bad & ~near
     assert not stray.any(), f"{what}: {int(stray.sum())} pixel(s) differ by > {tol} away from every validity-mask edge, e.g. {np.argwhere(stray)[:4].tolist()}; max there {d.reshape(-1, *d.shape[-2:])[:, stray].max():.3e}"
     return int(bad.sum()), float(near.mean())
+
+
+def count_flipped_pixels(got, want, tol):
+    """Number of ERP PIXELS (any plane of any batch item) at which `got` differs from `want` by more than `tol` (reference NaN pixels excluded):
+    the pixels at which a validity predicate of pers2equi flipped against the reference.  The parity tests pin this count:
+    the loose `max_tol` of a flipped pixel says nothing about HOW MANY flip — a kernel change that doubled the rate would stay green."""
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    ok = np.isfinite(want)
+    d = np.where(ok, np.abs(got - np.where(ok, want, 0.0)), 0.0)
+    return int((d > tol).reshape(-1, *d.shape[-2:]).any(axis=0).sum())

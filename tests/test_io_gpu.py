@@ -48,7 +48,10 @@ def test_pointcloud_and_ply_golden(tmp_path):
 
 
 @pytest.mark.parametrize("src,dst", [((64, 128), (64, 128)), ((128, 256), (64, 128)), ((256, 512), (64, 128)), ((90, 200), (32, 64))])
-def test_preprocess_vs_oracle(src, dst):
+def test_preprocess_vs_restatement_INTER_AREA_UNPINNED(src, dst):
+    """HIP prep kernels against oracle/io_ref.py — whose INTER_AREA is a restatement of OpenCV's published algorithm that NO cv2 output pins
+    (cv2 is absent from this image).  /255, HWC->CHW, depth scaling and the (0.1, 8] mask follow dataset_loader_stanford.py:54,76-109 exactly;
+    the resize is 'equal to the restatement', not 'equal to the reference' (keep out of green parity claims)."""
     from omnifusion_amd.data import preprocess_rgb, preprocess_depth
     from oracle import io_ref
     rng = np.random.default_rng(7)

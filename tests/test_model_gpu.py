@@ -435,6 +435,30 @@ def test_iterative_model_nrows6_golden():
     assert np.abs(o[1].cpu().numpy() - g["it1"]).max() <= 1e-3
 
 
+@pytest.mark.parametrize("nrows,N", [(3, 10), (5, 26)])
+def test_model_other_presets_golden(nrows, N):
+    """G6c: the full network at the two presets that had no reference-backed check — nrows 3 (10 patches: pers2equi centres
+    differ from equi2pers's, q7; uncovered ERP pixels) and nrows 5 (26 patches), equi2pers_v3.py:40-47 — against the reference's OWN outputs:
+    single pass with and without confidence, and the 2-iteration iterative model.  1e-3 abs on depth."""
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    g = golden(f"G6c_model_n{nrows}")
+    rgb = torch.from_numpy(g["rgb"]).to(DEV)
+    net = spherical_fusion(nrows, N, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, N, False))
+    out = net(rgb, confidence=True)
+    assert out.shape == (2, 1, 64, 128)
+    d = np.abs(out.cpu().numpy() - g["depth_conf"]).max()
+    assert d <= 1e-3, f"nrows {nrows} confidence=True: max |d| = {d}"
+    d = np.abs(net(rgb, confidence=False).cpu().numpy() - g["depth_noconf"]).max()
+    assert d <= 1e-3, f"nrows {nrows} confidence=False: max |d| = {d}"
+    if nrows == 3:                                                 # uncovered pixels are exactly zero, as in the reference
+        assert (out.cpu().numpy()[g["depth_conf"] == 0] == 0).all() and (g["depth_conf"] == 0).sum() > 0
+    neti = spherical_fusion_it(nrows, N, (128, 128), (80, 80)).cuda()
+    neti.load_state_dict(make_state_dict(42, N, True))
+    o = neti(rgb[:1], iter=2)
+    assert np.abs(o[0].cpu().numpy() - g["it0"]).max() <= 1e-3 and np.abs(o[1].cpu().numpy() - g["it1"]).max() <= 1e-3
+
+
 def test_iterative_model_config3_size():
     """BASELINE config 3 verbatim: ONE 1024x2048 panorama, nrows = 6 (46 patches), the 2-iteration iterative model at patch size 128
     (SURVEY 0.1), confidence=False as test.py:198 calls it — against the torch fp32 oracle (oracle/model_ref.py), every iteration, with
@@ -671,6 +695,40 @@ def test_captured_geometry_survives_cache_eviction():
     finally:
         L.set_option("geom_cache_max", 16)
         lib.omni_geometry_cache_clear()
+
+
+def test_equi2pers_work_tables_under_capture_and_across_plane_counts():
+    """e2p_box_kernel reads a per-(geometry, plane count) work table.  (1) A plane count first seen while the stream is
+    being captured is refused with a clear error (building the table allocates and copies synchronously: it would invalidate the capture);
+    (2) tables are never freed before their geometry handle — a captured graph replays correctly after more plane counts than the old
+    16-entry FIFO held; (3) the table does not depend on the channel count (B * 3 and 3 B * 1 planes share it: same bits either way)."""
+    L, lib = _lib()
+    from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
+    lib.omni_geometry_cache_clear()
+    lay = L.LAYOUT_BNCHW
+    x3 = torch.rand((1, 3, 64, 128), device=DEV)
+    ref3 = equi2pers_patches(x3, 80, 4, 32, layout=lay).clone()        # warms the geometry and plane count 3
+    out = torch.empty_like(ref3)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out.copy_(equi2pers_patches(x3, 80, 4, 32, layout=lay))
+    x5 = torch.rand((5, 1, 64, 128), device=DEV)
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(NotImplementedError, match="plane count"):
+        with torch.cuda.graph(g2, stream=s):
+            equi2pers_patches(x5, 80, 4, 32, layout=lay)
+    torch.cuda.synchronize()
+    for b in range(1, 25):                                            # 24 more plane counts on the same (pinned) geometry
+        xb = torch.rand((b, 2, 64, 128), device=DEV)
+        a = equi2pers_patches(xb, 80, 4, 32, layout=lay)
+        c = equi2pers_patches(xb.reshape(2 * b, 1, 64, 128), 80, 4, 32, layout=lay)     # same planes, C = 1: same table, same bits
+        assert torch.equal(a.reshape(b, 18, 2, 32, 32).permute(0, 2, 1, 3, 4).reshape(2 * b, 18, 1, 32, 32), c)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref3)
+    lib.omni_geometry_cache_clear()
 
 
 def test_model_overflow_flag():

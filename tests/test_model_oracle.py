@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from _util import golden, GOLDEN
@@ -64,6 +65,23 @@ def test_iterative_oracle_nrows6_golden():
     g = golden("G7b_model_iterative_n6")
     o = mr.spherical_fusion_iterative_forward(make_state_dict(42, 46, True), torch.from_numpy(g["rgb"]), 2, nrows=6, confidence=False)
     assert np.abs(o[0].numpy() - g["it0"]).max() < 2e-4 and np.abs(o[1].numpy() - g["it1"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("nrows,N", [(3, 10), (5, 26)])
+def test_oracle_other_presets_golden(nrows, N):
+    """G6c: nrows 3 (10 patches; q7 centre mismatch, uncovered ERP pixels) and nrows 5 (26 patches) — the reference's own outputs, single pass
+    with / without confidence and the 2-iteration iterative model (equi2pers_v3.py:40-47)."""
+    g = golden(f"G6c_model_n{nrows}")
+    rgb = torch.from_numpy(g["rgb"])
+    sd = make_state_dict(42, N, False)
+    out = mr.spherical_fusion_forward(sd, rgb, nrows=nrows, confidence=True)
+    assert np.abs(out.numpy() - g["depth_conf"]).max() < 2e-4
+    out = mr.spherical_fusion_forward(sd, rgb, nrows=nrows, confidence=False)
+    assert np.abs(out.numpy() - g["depth_noconf"]).max() < 2e-4
+    o = mr.spherical_fusion_iterative_forward(make_state_dict(42, N, True), rgb[:1], 2, nrows=nrows, confidence=False)
+    assert np.abs(o[0].numpy() - g["it0"]).max() < 2e-4 and np.abs(o[1].numpy() - g["it1"]).max() < 2e-4
+    if nrows == 3:
+        assert (g["depth_conf"] == 0).sum() > 0                    # uncovered pixels: exactly 0 in the reference's output too
 
 
 def test_metrics_restatement_golden():

@@ -1176,13 +1176,30 @@ namespace {
 // gather blocks — the shortest — come last.  Block b runs on XCD b % 8: column x of the table holds tiles of ERP region x only.
 struct E2PWork { uint4* dev = nullptr; int nblocks = 0; };
 
+// LDS one wave of e2p_box_kernel really uses for a geometry whose largest staged box is `max_chunks` 16-byte chunks: NB(NJ) slots of NJ KiB for the
+// largest NJ (the ring is addressed slot by slot, so smaller boxes use less).  cfg 1 (boxes to 6 KiB): 12 KiB; cfg 3 / cfg 5 (1-2 KiB): 4 KiB — LDS
+// then admits far more waves than the registers (16 per CU)
+static size_t e2b_lds_bytes(int max_chunks, int nbmax)
+{
+    const int njmax = std::max(1, (max_chunks + 63) / 64);
+    int kb = 1;
+    for (int nj = 1; nj <= std::min(njmax, E2B_NJMAX); ++nj) {
+        const int nbr = E2B_RING_KB / nj >= 4 ? 4 : E2B_RING_KB / nj >= 2 ? 2 : 1;
+        kb = std::max(kb, std::min(nbr, nbmax) * nj);
+    }
+    return (size_t)std::max(kb, njmax) * 1024;
+}
+
 template <int E>
 int e2p_work_table(const omni_geometry* gc, int planes, int nbmax, hipStream_t stream, E2PWork& out)
 {
     omni_geometry* g = const_cast<omni_geometry*>(gc);             // (the cache is a mutable part of the handle)
     auto& tt = g->e2p_boxes[E];
     const OmniOptions& o = omni_options();
-    const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : 12, split = o.e2p_split > 0 ? o.e2p_split : 3,
+    // wave slots per CU the schedule plans for: what the kernel's LDS footprint admits (e2b_lds_bytes: 12 KiB at cfg 1 -> 12 or 13), at most the 16
+    // that 108 registers per wave admit
+    const int slots_lds = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(1024, e2b_lds_bytes(tt.max_chunks, nbmax)));
+    const int slots_cu = o.e2p_slots > 0 ? o.e2p_slots : std::min(slots_lds, 12) == 12 ? 12 : slots_lds, split = o.e2p_split > 0 ? o.e2p_split : 3,
               fbp = o.e2p_fb_planes > 0 && o.e2p_fb_planes < 90 ? o.e2p_fb_planes : std::min(tt.norder < slots_cu * omni_num_cus() ? 6 : 12, planes);   // (shorter where the launch is under one round: P = 128)
     // key = everything the table depends on: the plane count and the option set (NOT the channel count: the table holds plane ranges, the
     // kernel splits a plane index into (batch item, channel) itself — B * 3 and 3 B * 1 planes share one table).  Every field whole (ADVICE r3:
@@ -1259,7 +1276,8 @@ int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t
     int rc = e2p_work_table<E>(g, B * C, NBMAX, stream, wk);
     if (rc != OMNI_OK) return rc;
     const int njmax = (tt.max_chunks + 63) / 64;
-    const size_t lds = (size_t)(njmax > E2B_RING_KB ? njmax : E2B_RING_KB) * 1024;
+    const size_t lds = e2b_lds_bytes(tt.max_chunks, NBMAX);
+    (void)njmax;
     hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2>), dim3(wk.nblocks), dim3(64), lds, stream, a, (const uint4*)wk.dev, tt.tx, tt.tx * tt.ty,
                        (unsigned)tensor_bytes);
     OMNI_HIP(hipGetLastError());

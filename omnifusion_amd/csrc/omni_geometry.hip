@@ -51,6 +51,8 @@ const OptName kOpts[] = {
     {"p2e_band", "OMNI_P2E_BAND", &OmniOptions::p2e_band, 0},
     {"p2e_nbuf", "OMNI_P2E_NBUF", &OmniOptions::p2e_nbuf, 0},
     {"p2e_planes", "OMNI_P2E_PLANES", &OmniOptions::p2e_planes, 0},
+    {"p2e_walk", "OMNI_P2E_WALK", &OmniOptions::p2e_walk, 1},
+    {"p2e_store", "OMNI_P2E_STORE", &OmniOptions::p2e_store, 1},
     {"geom_cache_max", "OMNI_GEOM_CACHE_MAX", &OmniOptions::geom_cache_max, 16},
 };
 }  // namespace
@@ -199,7 +201,7 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     centers(nrows, 0, nullptr, nullptr, g->center_p);
     g->row_trig = nullptr; g->col_trig = nullptr; g->cand = nullptr; g->ntx = (W + 63) / 64;
     g->e2p_fb_tiles = nullptr; g->e2p_nfb = 0; g->e2p_ixy = nullptr; g->e2p_ts = 32;
-    for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.ord = nullptr; t.nslots = 0; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; t.sum_chunks = 0; }
+    for (auto& t : g->p2e_tiles) { t.ent = nullptr; t.ord = nullptr; t.walk = nullptr; t.nslots = 0; t.max_chunks = 0; t.max_cand = 0; t.ok = 0; t.sum_chunks = 0; }
     for (auto& t : g->e2p_boxes) { t.ent = nullptr; t.fb = nullptr; t.order = nullptr; t.norder = 0; t.nfb = 0; t.max_chunks = 0; t.ok = 0; t.tw = t.th = t.tx = t.ty = 0; }
     g->p2e_tx = g->p2e_ty = 0; g->pinned = 0;
     g->p2e_bwd_box = nullptr; g->p2e_rden = nullptr; g->p2e_btx = g->p2e_bty = g->p2e_bwd_ok = 0;
@@ -233,7 +235,7 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->row_trig) (void)hipFree(g->row_trig);
     if (g->col_trig) (void)hipFree(g->col_trig);
     if (g->cand) (void)hipFree(g->cand);
-    for (auto& t : g->p2e_tiles) { if (t.ent) (void)hipFree(t.ent); if (t.ord) (void)hipFree(t.ord); }
+    for (auto& t : g->p2e_tiles) { if (t.ent) (void)hipFree(t.ent); if (t.ord) (void)hipFree(t.ord); if (t.walk) (void)hipFree(t.walk); }
     if (g->p2e_bwd_box) (void)hipFree(g->p2e_bwd_box);
     if (g->p2e_rden) (void)hipFree(g->p2e_rden);
     if (g->p2e_bwd_ids) (void)hipFree(g->p2e_bwd_ids);

@@ -53,6 +53,8 @@ struct OmniOptions {
     int p2e_band;         // OMNI_P2E_BAND       tile rows per XCD band of the pers2equi block order (0: max(1, tile rows / 8) — ONE contiguous range of tile rows per XCD)
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
+    int p2e_store;        // OMNI_P2E_STORE      ERP stores of the pers2equi LDS kernels: 1 (default) non-temporal | 0 plain
+    int p2e_walk;         // OMNI_P2E_WALK       1 (default): the flat-pipeline kernel p2e_walk_kernel (one stage stream per tile across its patches, stages consumed in pairs) | 0: p2e_lds_kernel (patch by patch)
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
 OmniOptions& omni_options();
@@ -97,7 +99,7 @@ struct omni_geometry {
     int ntx;
     // pers2equi LDS path: per ERP tile (P2E_TH x P2E_TW pixels) the list of covering patches with the bounding box of their
     // bilinear taps inside the patch (omni_pers2equi.hip); index 0: 4-byte elements, 1: 2-byte elements (16-byte chunk alignment)
-    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; int sum_chunks; uint2* ord; int nslots; } p2e_tiles[2];   // ord: the table in block order (+ tile id), what the kernels read
+    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; int sum_chunks; uint2* ord; int nslots; unsigned char* walk; int nslots_walk; } p2e_tiles[2];   // ord: the table in block order (+ tile id), what the kernels read
     int p2e_tx, p2e_ty;            // tiles per ERP row / column
     // pers2equi backward by gathers (omni_pers2equi.hip): per (patch, 4 x 32 patch tile) the ERP box of the pixels whose taps touch it
     // (columns relative to the patch's centre column: the box may cross the +-pi seam), and 1 / (L1 norm of the tap weights) per ERP pixel
@@ -140,10 +142,15 @@ template <typename T> struct Store;
 template <> struct Store<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    // non-temporal form for outputs the kernel never re-reads: the lines stream to memory while the kernel runs instead of sitting dirty in
+    // the XCD's L2 until the end-of-kernel write-back
+    static __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 };
 template <> struct Store<__half> {
     static __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
     static __device__ __forceinline__ void st(__half* p, float v) { *p = __float2half_rn(v); }
+    static __device__ __forceinline__ void st_nt(__half* p, float v)
+    { const __half h = __float2half_rn(v); __builtin_nontemporal_store(*reinterpret_cast<const unsigned short*>(&h), reinterpret_cast<unsigned short*>(p)); }
 };
 
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md,

@@ -41,6 +41,7 @@ struct P2EArgs {
     long long sB, sC, sN, sY, sX;              // element strides of the patch tensor
     float kx, ky;                              // 1/(FOVx*PI), 1/(FOVy*PI_2)   (:115-116)
     float half_h, half_w;                      // 0.5*height, 0.5*width        (:122-123)
+    int store_nt;                              // 1: non-temporal ERP stores (option p2e_store)
     int dbg;                                   // debug build only (OMNI_P2E_DBG ablation bits): 1 no tap geometry, 2 no LDS tap reads, 4 no DMA, 8 no stores
     long long* trace;                          // debug build, bit 16: per-block time stamps (omni_debug_set_trace)
     PatchTab tab;
@@ -575,9 +576,11 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
             if constexpr (CONF) {
                 const float pr = acc[p][k] * rden, cf = acc2[p][k] * rden;
                 const float z = (cf <= 1e-8f) ? 1.0f : 0.0f;
-                reinterpret_cast<float*>(a.erp)[o] = pr / (cf + 1e-8f * z);
+                const float r = pr / (cf + 1e-8f * z);
+                if (a.store_nt) Store<float>::st_nt(reinterpret_cast<float*>(a.erp) + o, r); else reinterpret_cast<float*>(a.erp)[o] = r;
             } else {
-                Store<T>::st(reinterpret_cast<T*>(a.erp) + o, acc[p][k] * rden);
+                if (a.store_nt) Store<T>::st_nt(reinterpret_cast<T*>(a.erp) + o, acc[p][k] * rden);
+                else Store<T>::st(reinterpret_cast<T*>(a.erp) + o, acc[p][k] * rden);
             }
         }
     }
@@ -587,6 +590,237 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
             long long* t = a.trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
             t[0] = tr0; t[1] = tr1; t[2] = wall_clock64();
             t[3] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((long long)ncand << 40);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ flat-pipeline blend (round 4: default for the planar layout)
+// What bounds p2e_lds_kernel is not bytes but its waves' dependent CHAINS: a launch of BASELINE size has one wave per tile, every wave resident
+// at once, and ends with the longest chain — a 4-patch tile, 3.3 us + 2.9 us per patch (profiles/r03b_resample_sweeps.txt, r03_p2e_shed).  Its ISA
+// shows why a patch costs 2.9 us: per stage [wait DMA -> 2 ds_read2 -> wait -> 4 fma -> 2 ds_read2 -> wait -> 4 fma -> wait -> refill], i.e. two
+// exposed LDS round trips per plane; a drained ring at every patch boundary (the next patch's first boxes wait for its table record, then a full
+// memory round trip); and in front of everything two DEPENDENT cold misses (slot record -> tile id -> trig tables).  This kernel keeps the tile,
+// the taps, the boxes and every output bit of p2e_lds_kernel and changes the schedule:
+//   * ONE stage stream per tile: stage s = (patch s / PL, plane s % PL), NB ring slots, refill distance NB — ACROSS patch boundaries: while the
+//     last stages of patch c are consumed, the first stages of patch c+1 are already in flight (its DMA offsets are computed one patch ahead), so
+//     the tap geometry of c+1 is evaluated under its own boxes' flight time;
+//   * stages are consumed in PAIRS where 4 slots fit the ring (U = 2): one counted wait, all ds_read2 of both planes issued back to back, one LDS
+//     wait, both refills, then the 16 fmas — one exposed LDS round trip per two planes instead of four;
+//   * the number of 1-KiB pieces per stage is a constant of the TILE (the largest box of its patches; smaller boxes pad with out-of-range lanes,
+//     which deposit zeros without touching memory): every s_waitcnt count of the flat stream is a compile-time constant of (NJ, last patch or not);
+//   * the slot record carries the tile's trig (32 column + 4 row pairs, 288 B): header, first patch record and trig leave in parallel, ONE cold
+//     round trip in front of the first DMA.
+constexpr int P2W_NJMAX = 6;                                   // largest box (KiB) the walk kernel is instantiated for
+constexpr int P2W_SLOT = 768;                                  // bytes per block slot: header 32 | 12 patch records x 32 | trig 288 | pad
+constexpr int P2W_OFF_PATCH = 32, P2W_OFF_TRIG = 32 + 32 * P2E_MAXC;
+static_assert(P2W_OFF_TRIG + 8 * (P2E_TW + P2E_TH) <= P2W_SLOT, "slot layout");
+constexpr int p2w_nb(int pieces, int pl)
+{
+    int nb = P2E_RING_KB / pieces >= 4 ? 4 : P2E_RING_KB / pieces >= 2 ? 2 : 1;
+    while (nb > pl) nb >>= 1;
+    return nb;
+}
+constexpr int p2w_u(int nb, int pl) { return nb == 4 ? 2 : (nb == 2 && pl == 2) ? 2 : 1; }
+
+constexpr int P2W_WPB = 1;                                     // waves per block: independent waves (no barrier, each its own tile and ring) — 4x fewer workgroups to dispatch
+template <typename T, int PL, bool CONF>
+__global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? (CONF ? 5 : 6) : 4) void p2e_walk_kernel(P2EArgs a, const unsigned char* __restrict__ table, int tiles_x, unsigned tensor_bytes, int p_first, unsigned ring_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char p2w_smem_all[];    // the ONLY LDS object of this kernel: one ring per wave
+    constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = P2E_NPX;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char* const p2w_smem = p2w_smem_all + (unsigned)wv * ring_bytes;
+    const unsigned char* __restrict__ slot = table + ((size_t)blockIdx.x * P2W_WPB + (size_t)wv) * P2W_SLOT;
+    const uint4* __restrict__ sl = reinterpret_cast<const uint4*>(slot);            // wave-uniform addresses: scalar loads
+    const uint4 hd = sl[0];
+    // my pixels' trig: an address that does not depend on the header (issued beside it)
+    const int col = lane & 31, rsub = lane >> 5;
+    const float2* __restrict__ tg = reinterpret_cast<const float2*>(slot + P2W_OFF_TRIG);
+    const float2 ct = tg[col];
+    float2 rt[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) rt[k] = tg[P2E_TW + rsub + 2 * k];
+    uint4 ea = sl[2], eb = sl[3];                                  // record of the first patch
+    const int wid = (int)hd.x;
+    if (wid < 0) return;                                           // padding slot (block-uniform)
+    if (OMNI_DBG(a, 32)) return;                                   // (debug: the launch floor — blocks that read their header and end)
+    const int ncand = (int)hd.y, njt = (int)hd.z;
+    const int ti = wid / tiles_x, tj = wid - ti * tiles_x;
+    const int j = tj * P2E_TW + col;
+    const bool jin = j < a.W;
+    const int p_begin = p_first + (int)blockIdx.y * PL;
+    unsigned char* const ring = p2w_smem;
+    const p2e_rsrc_t rs1 = p2e_make_rsrc(a.pers, tensor_bytes);
+    const p2e_rsrc_t rs2 = p2e_make_rsrc(CONF ? a.pers2 : a.pers, tensor_bytes);
+    const unsigned sYb = (unsigned)a.sY * (unsigned)sizeof(T), sNb = (unsigned)a.sN * (unsigned)sizeof(T);
+    unsigned poff_l;                                               // lane p: byte offset of plane p_begin + p (< 2^31, host-checked)
+    {
+        const int p = p_begin + min(lane, PL - 1);
+        const unsigned e = CONF ? (unsigned)p * (unsigned)a.sB : (unsigned)(p / a.C) * (unsigned)a.sB + (unsigned)(p % a.C) * (unsigned)a.sC;
+        poff_l = e * (unsigned)sizeof(T);
+    }
+    // all ordinary vector loads are consumed HERE, before the first LDS-DMA is issued (a later first use would make the compiler drain the DMA
+    // queue with vmcnt(0))
+    asm volatile("" ::"v"(ct.x), "v"(ct.y));
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) asm volatile("" ::"v"(rt[k].x), "v"(rt[k].y));
+
+    float acc[PL][NPX], acc2[CONF ? PL : 1][NPX], l1[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        l1[k] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < PL; ++p) { acc[p][k] = 0.0f; if constexpr (CONF) acc2[p][k] = 0.0f; }
+    }
+    // taps of the current patch for my pixels: LDS element offsets inside the box + the four weights (p2e_taps_core: the bits of every kernel)
+    int r0[NPX], r1[NPX];
+    float wa[NPX], wb[NPX], wc[NPX], wd[NPX];
+    auto taps = [&](const uint4& ra, const uint4& rb) {
+        const unsigned e0 = ra.x, e1 = ra.y;
+        const float sl0 = __uint_as_float(ra.z), cl0 = __uint_as_float(ra.w), sp = __uint_as_float(rb.x), cp = __uint_as_float(rb.y);
+        const int bw4 = (e0 >> 6) & 1023, xa = e1 & 0xffff, ymin = e1 >> 16, pitch = bw4 * EPC;
+        const float cd = ct.y * cl0 + ct.x * sl0;                   // p2e_lon with the record's constants: cos(lon - l0)
+        const float sd = ct.x * cl0 - ct.y * sl0;                   //                                      sin(lon - l0)
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            Taps t;
+            if (OMNI_DBG(a, 1)) { t.x0 = xa + 1; t.x1 = xa + 2; t.y0 = ymin; t.y1 = ymin; t.wa = t.wb = t.wc = t.wd = 0.25f * rt[k].x; (void)cd; (void)sd; }
+            else p2e_taps_core(a, sp, cp, rt[k].x, rt[k].y, cd, sd, t);
+            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);       // all >= 0 after the threshold
+            l1[k] += wsum;
+            const int xo = t.x0 - xa_adj(t.x0, t.x1, xa);           // (see p2e_lds_kernel: the pair's SECOND element is the x1 tap at the right edge)
+            const bool used = wsum > 0.0f;
+            r0[k] = used ? (t.y0 - ymin) * pitch + xo : 0;
+            r1[k] = used ? (t.y1 - ymin) * pitch + xo : 0;
+            wa[k] = t.wa; wb[k] = t.wb; wc[k] = t.wc; wd[k] = t.wd;
+        }
+    };
+
+    auto run = [&]<int NJ>(std::integral_constant<int, NJ>) {
+        constexpr int NB = p2w_nb(NJ * M, PL), U = p2w_u(NB, PL), ITERS = PL / U;
+        constexpr unsigned slot_bytes = NJ * M * 1024u;
+        static_assert(PL % NB == 0 && NB % U == 0, "a stage's ring slot must be a compile-time constant");
+        // byte offset of my chunk of piece q from the box origin + the box origin (wave-uniform) of the patch the NEXT refill reads: the current
+        // patch for the iterations whose refill stages lie inside it, the following patch from iteration JS on (ONE set of registers: U | NB | PL,
+        // so an iteration refills entirely from one patch)
+        unsigned gc[NJ], base_c = 0;
+        constexpr int JS = (PL - NB) / U;                          // first iteration whose refills belong to the next patch
+        auto dma_params = [&](const uint4& ra, unsigned (&g)[NJ], unsigned& base) {
+            const unsigned e0 = ra.x, e1 = ra.y;
+            const int n = e0 & 63, bw4 = (e0 >> 6) & 1023, xa = e1 & 0xffff, ymin = e1 >> 16;
+            const int nchunk = bw4 * (int)((e0 >> 16) & 1023);
+            base = (unsigned)n * sNb + (unsigned)ymin * sYb + (unsigned)xa * (unsigned)sizeof(T);
+            const float rbw = __builtin_amdgcn_rcpf((float)bw4);
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                const int qc = q * 64 + lane;
+                const int rr = (int)(((float)qc + 0.5f) * rbw);                        // qc / bw4, exact for qc, bw4 <= 1024
+                g[q] = qc < nchunk ? (unsigned)rr * sYb + (unsigned)(qc - rr * bw4) * 16u : 0x80000000u;   // past the end (of THIS patch's box): zeros
+            }
+        };
+        auto issue = [&](const unsigned (&g)[NJ], unsigned base, int plane, int slot_i) {
+            if (OMNI_DBG(a, 4)) return;
+            const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)poff_l, plane) + base;
+            unsigned char* dst = ring + (unsigned)slot_i * slot_bytes;
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                p2e_dma16(rs1, dst + q * 1024, g[q], so);
+                if (CONF) p2e_dma16(rs2, dst + NJ * 1024u + q * 1024, g[q], so);
+            }
+        };
+        // one patch of the stream: ITERS iterations of U stages.  LAST: no patch follows (nothing to refill from beyond plane PL - 1).
+        auto body = [&]<bool LAST>(std::bool_constant<LAST>, const uint4& nrec) {
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                (([&] {
+                    constexpr int first = J * U;
+                    if constexpr (!LAST && J == JS) dma_params(nrec, gc, base_c);     // from here on the refills read the next patch
+                    // stages younger than the ones consumed here and already in flight: first + U .. first + NB - 1 of the flat stream
+                    constexpr int ahead = NB - U;
+                    constexpr int left = PL - first - U;            // ... of which this many belong to THIS patch
+                    constexpr int younger = LAST ? (left < ahead ? (left > 0 ? left : 0) : ahead) : ahead;
+                    p2e_wait_vm<younger * NJ * M>();
+                    float v[U][M][NPX][4];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned char* box = ring + (unsigned)((first + u) % NB) * slot_bytes;
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+#pragma unroll
+                            for (int k = 0; k < NPX; ++k) {
+                                if (OMNI_DBG(a, 2)) { v[u][m][k][0] = v[u][m][k][1] = v[u][m][k][2] = v[u][m][k][3] = wa[k]; continue; }
+                                LdsPair<T>::ld(box + m * NJ * 1024u, r0[k], v[u][m][k][0], v[u][m][k][1]);
+                                LdsPair<T>::ld(box + m * NJ * 1024u, r1[k], v[u][m][k][2], v[u][m][k][3]);
+                            }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of these slots has returned: they are DMA targets again
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int t = first + u + NB;
+                        if (t < PL) issue(gc, base_c, t, (first + u) % NB);
+                        else if (!LAST) issue(gc, base_c, t - PL, (first + u) % NB);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int k = 0; k < NPX; ++k) {
+                            // taps (y0,x0) (y1,x0) (y0,x1) (y1,x1) in the gather kernel's order of operations
+                            acc[first + u][k] += fmaf(v[u][0][k][3], wd[k], fmaf(v[u][0][k][1], wc[k], fmaf(v[u][0][k][2], wb[k], v[u][0][k][0] * wa[k])));
+                            if constexpr (CONF)
+                                acc2[first + u][k] += fmaf(v[u][1][k][3], wd[k], fmaf(v[u][1][k][1], wc[k], fmaf(v[u][1][k][2], wb[k], v[u][1][k][0] * wa[k])));
+                            // the blend happens HERE (volatile statements keep their order): left to itself the scheduler defers the fmas of every
+                            // iteration to the end of the patch and keeps all their operands alive — 64 registers, scratch spills
+                            asm volatile("" : "+v"(acc[first + u][k]));
+                            if constexpr (CONF) asm volatile("" : "+v"(acc2[first + u][k]));
+                        }
+                }()), ...);
+            }(std::make_integer_sequence<int, ITERS>());
+        };
+        // ---- head of the stream: the first NB stages of patch 0 go out, its taps are evaluated while they travel
+        dma_params(ea, gc, base_c);
+#pragma unroll
+        for (int d = 0; d < NB; ++d) issue(gc, base_c, d, d);
+        taps(ea, eb);
+        for (int c = 0; c < ncand; ++c) {
+            const bool last = c + 1 == ncand;
+            const uint4 na = sl[2 * (c + 2)], nb4 = sl[2 * (c + 2) + 1];    // record of patch c + 1 (a zero record past the list)
+            if (!last) {
+                body(std::bool_constant<false>(), na);
+                taps(na, nb4);                                      // ... under the flight time of its own first boxes
+            } else {
+                body(std::bool_constant<true>(), na);
+            }
+        }
+    };
+    // (boxes of up to P2W_NJMAX KiB: every BASELINE shape is 1-3; a geometry with larger boxes — patches much finer than the ERP — stays on p2e_lds_kernel)
+    switch (njt) {
+    case 1: run(std::integral_constant<int, 1>()); break;
+    case 2: run(std::integral_constant<int, 2>()); break;
+    case 3: run(std::integral_constant<int, 3>()); break;
+    case 4: run(std::integral_constant<int, 4>()); break;
+    case 5: run(std::integral_constant<int, 5>()); break;
+    default: run(std::integral_constant<int, P2W_NJMAX>()); break;
+    }
+    // ---- normalise and store (pers2equi_v3.py:192-196; K11: spherical_model.py:310-311)
+    const size_t erp_plane = (size_t)a.H * a.W;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int i = ti * P2E_TH + rsub + 2 * k;
+        if (!(jin && i < a.H)) continue;
+        if (OMNI_DBG(a, 8) && l1[k] != -1.0f) continue;
+        const float rden = 1.0f / fmaxf(l1[k], 1e-12f);
+        const size_t pix = (size_t)i * a.W + j;
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            const size_t o = (size_t)(p_begin + p) * erp_plane + pix;
+            if constexpr (CONF) {
+                const float pr = acc[p][k] * rden, cf = acc2[p][k] * rden;
+                const float z = (cf <= 1e-8f) ? 1.0f : 0.0f;
+                const float r = pr / (cf + 1e-8f * z);
+                if (a.store_nt) Store<float>::st_nt(reinterpret_cast<float*>(a.erp) + o, r); else reinterpret_cast<float*>(a.erp)[o] = r;
+            } else {
+                if (a.store_nt) Store<T>::st_nt(reinterpret_cast<T*>(a.erp) + o, acc[p][k] * rden);
+                else Store<T>::st(reinterpret_cast<T*>(a.erp) + o, acc[p][k] * rden);
+            }
         }
     }
 }
@@ -666,6 +900,7 @@ int fill_args(P2EArgs& a, const omni_geometry* g, const void* pers, const void* 
     a.ky = (float)(1.0 / ((double)(g->fov_h / 180.0f) * (double)PI2f));
     a.half_h = 0.5f * (float)g->ph; a.half_w = 0.5f * (float)g->pw;
     a.tab = g->p2e;
+    a.store_nt = omni_options().p2e_store ? 1 : 0;
     a.dbg = 0; a.trace = nullptr;
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_P2E_DBG");
@@ -698,8 +933,32 @@ int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int p_first, int
 }
 
 template <typename T, int PL, bool CONF>
+int launch_p2e_walk_pl(const P2EArgs& a, const omni_geometry* g, int p_first, int planes, size_t tensor_bytes, hipStream_t stream)
+{
+    const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
+    const int stage_kb = (tt.max_chunks + 63) / 64 * (CONF ? 2 : 1);
+    // (ONE plane per wave keeps one stage in flight whatever the ring: its LDS is the largest stage of the geometry, 1-2 KiB — up to 32 waves per CU)
+    const size_t lds = (size_t)(PL == 1 ? stage_kb : (stage_kb > P2E_RING_KB ? stage_kb : P2E_RING_KB)) * 1024;
+    static_assert(256 % P2W_WPB == 0, "nslots is a multiple of 256");
+    hipLaunchKernelGGL((p2e_walk_kernel<T, PL, CONF>), dim3(tt.nslots_walk / P2W_WPB, planes / PL), dim3(64 * P2W_WPB), lds * P2W_WPB, stream, a,
+                       (const unsigned char*)tt.walk, g->p2e_tx, (unsigned)tensor_bytes, p_first, (unsigned)lds);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// the forms of the walk kernel that fit 128 registers WITHOUT scratch (a scratch access inside the counted DMA pipeline would shift every
+// s_waitcnt; omnifusion_amd/isa.py fails the build otherwise): 2-byte elements need extra registers for the byte-aligns of their tap pairs
+template <typename T, int PL, bool CONF> constexpr bool p2w_fits() { return true; }
+
+template <typename T, int PL, bool CONF>
 int launch_p2e_lds_pl(const P2EArgs& a, const omni_geometry* g, int p_first, int planes, size_t tensor_bytes, hipStream_t stream)
 {
+    // option p2e_walk: 1 (default) the flat-pipeline kernel for waves of ONE or TWO planes — a lone panorama's depth map, BASELINE cfg 3 / cfg 5: 30.9 ->
+    // 25.7 us, 110 -> 100 us (fp16), 105 -> 88 us — where its small LDS footprint (one stage) admits 24-32 waves per CU; with 4 / 8 planes per wave the
+    // two kernels measure equal at 8 panoramas and p2e_lds_kernel 3 % ahead at 16 (profiles/r04_p2e_walk.txt) | 2: always | 0: never
+    if constexpr (p2w_fits<T, PL, CONF>())
+    if ((omni_options().p2e_walk == 2 || (omni_options().p2e_walk == 1 && PL <= 2)) && g->p2e_tiles[sizeof(T) == 2 ? 1 : 0].walk && g->p2e_tiles[sizeof(T) == 2 ? 1 : 0].max_chunks <= 64 * P2W_NJMAX)
+        return launch_p2e_walk_pl<T, PL, CONF>(a, g, p_first, planes, tensor_bytes, stream);
     int nb = omni_options().p2e_nbuf;
     if (nb <= 0) nb = 2;   // measured: 2 stages x 16 waves/CU beat 4 stages (18.4 vs 19.3 us at B=8 18x256^2)
     if (nb >= 4) return launch_p2e_lds_nb<T, PL, CONF, 4>(a, g, p_first, planes, tensor_bytes, stream);
@@ -749,7 +1008,9 @@ int launch_p2e(const omni_geometry* g, const void* pers, const void* pers2, void
     // (ONE plane — a lone panorama's depth map, BASELINE cfg 3 / cfg 5 — has nothing to amortise the boxes over: the launch is bound by the tap
     //  geometry of its (pixel, patch) pairs, ~100 vector instructions each, and the direct gathers are the shorter program: cfg 3 31.2 vs 33.6 us,
     //  cfg 5 fp16 108 vs 123 us; at 512x1024 the two are equal)
-    const bool single = planes == 1 && (long long)g->H * g->W >= (1ll << 20) && omni_options().p2e_gather != 2;
+    // (round 4: with the flat-pipeline kernel the LDS path wins for one plane too; the gathers remain for option p2e_walk = 0)
+    const bool single = planes == 1 && (long long)g->H * g->W >= (1ll << 20) && omni_options().p2e_gather != 2 &&
+                        !(omni_options().p2e_walk && tt.walk && tt.max_chunks <= 64 * P2W_NJMAX);
     if (a.sX == 1 && tt.ok && aligned && omni_options().p2e_gather != 1 && !single && tensor_bytes < (1ll << 31))   // 32-bit buffer offsets
         return launch_p2e_lds<T, CONF>(a, g, planes, (size_t)tensor_bytes, stream);
     const int rows4 = (g->H + 3) / 4;
@@ -857,6 +1118,47 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
                 }
             if (hipMalloc((void**)&tt.ord, sizeof(uint2) * ord.size()) != hipSuccess ||
                 hipMemcpy(tt.ord, ord.data(), sizeof(uint2) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: order table"); }
+            // ---- the same slots for p2e_walk_kernel: header {tile | -1, covering patches, pieces per stage (tile-uniform)}, the patch records, the tile's trig
+            {
+                std::vector<float2> hrow((size_t)g->H), hcol((size_t)g->W);
+                if (hipMemcpy(hrow.data(), g->row_trig, sizeof(float2) * hrow.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(hcol.data(), g->col_trig, sizeof(float2) * hcol.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: trig copy"); }
+                // block b of the walk kernel = P2W_WPB waves = the slots WPB b .. WPB b + WPB - 1, all on CU (b / 8) % 32 of XCD b % 8: the tile that
+                // the one-wave-per-block order gives to (XCD x, CU c, round r) keeps its CU — slot WPB (((r / WPB) 32 + c) 8 + x) + r % WPB
+                const size_t rounds_w = (rounds + P2W_WPB - 1) / P2W_WPB * P2W_WPB;
+                tt.nslots_walk = (int)(rounds_w * 32 * 8);
+                std::vector<unsigned char> wt((size_t)tt.nslots_walk * P2W_SLOT, 0);
+                for (int s2 = 0; s2 < tt.nslots_walk; ++s2) { const unsigned m1 = 0xffffffffu; memcpy(wt.data() + (size_t)s2 * P2W_SLOT, &m1, 4); }
+                int hist[P2E_NJMAX + 1] = {0};
+                for (int s2 = 0; s2 < tt.nslots; ++s2) {
+                    const uint2* rec = ord.data() + (size_t)s2 * 4 * P2E_REC;
+                    const size_t x8 = (size_t)s2 % 8, pos = (size_t)s2 / 8, rr = pos / 32, cu = pos % 32;
+                    unsigned char* dst = wt.data() + ((((rr / P2W_WPB) * 32 + cu) * 8 + x8) * P2W_WPB + rr % P2W_WPB) * P2W_SLOT;
+                    const int wid = (int)rec[0].x, cnt = (int)rec[0].y;
+                    int njt = 1;
+                    if (wid >= 0)
+                        for (int c = 0; c < cnt && c < P2E_MAXC; ++c) {
+                            const unsigned e0 = rec[4 * (c + 1)].x;
+                            const int nchunk = (int)((e0 >> 6) & 1023) * (int)((e0 >> 16) & 1023);
+                            njt = std::max(njt, (nchunk + 63) / 64);
+                        }
+                    if (wid >= 0) ++hist[std::min(njt, P2E_NJMAX)];
+                    const unsigned hdr[8] = {(unsigned)wid, (unsigned)cnt, (unsigned)njt, 0u, 0u, 0u, 0u, 0u};
+                    memcpy(dst, hdr, 32);
+                    memcpy(dst + P2W_OFF_PATCH, rec + 4, 32 * P2E_MAXC);
+                    if (wid >= 0) {
+                        const int ti = wid / tx, tj = wid - ti * tx;
+                        float2* tg = reinterpret_cast<float2*>(dst + P2W_OFF_TRIG);
+                        for (int cc = 0; cc < P2E_TW; ++cc) tg[cc] = hcol[(size_t)std::min(tj * P2E_TW + cc, g->W - 1)];
+                        for (int r = 0; r < P2E_TH; ++r) tg[P2E_TW + r] = hrow[(size_t)std::min(ti * P2E_TH + r, g->H - 1)];
+                    }
+                }
+                if (omni_options().e2p_verbose)
+                    fprintf(stderr, "[omni] pers2equi %dx%d <- %dx%d, %d-byte elements: tiles by KiB pieces per stage (largest box of the tile): 1:%d 2:%d 3:%d 4:%d 5:%d 6:%d 7:%d 8:%d\n",
+                            g->H, g->W, g->ph, g->pw, 16 / epc, hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
+                if (hipMalloc((void**)&tt.walk, wt.size()) != hipSuccess ||
+                    hipMemcpy(tt.walk, wt.data(), wt.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: walk table"); }
+            }
         }
         (void)hipFree(tt.ent); tt.ent = nullptr;                     // the kernels read only the ordered table (tt.ord)
         if (omni_options().e2p_verbose)

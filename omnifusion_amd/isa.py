@@ -107,7 +107,7 @@ def check(objs=None):
                 break
         for k in kernel_meta(obj):
             if any(c in k["name"] for c in COUNTED):
-                if k.get("scratch", 0) or k.get("vgpr_spill", 0) or k.get("sgpr_spill", 0):
+                if k.get("scratch", 0) or k.get("vgpr_spill", 0):          # (SGPR spills go to VGPR lanes — v_writelane — not to memory)
                     bad.append(f"{base}: {k['name']} uses scratch {k.get('scratch')} B / spills {k.get('vgpr_spill')} VGPR "
                                f"{k.get('sgpr_spill')} SGPR — its hand-counted s_waitcnt vmcnt(N) would be off")
     return bad

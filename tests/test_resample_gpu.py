@@ -347,6 +347,38 @@ def test_lds_and_gather_paths_give_the_same_bits(cfg):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cfg", [(8, 1, 512, 1024, 4, 256), (7, 1, 512, 1024, 4, 128), (1, 1, 1024, 2048, 6, 256), (2, 1, 250, 500, 5, 64),
+                                 (3, 1, 64, 128, 4, 16)])
+def test_flat_pipeline_kernel_gives_the_bits_of_the_other_two(cfg):
+    """p2e_walk_kernel (round 4: one stage stream per tile across its patches, stages consumed in pairs, tile-uniform piece count; default for
+    waves of one or two planes) against p2e_lds_kernel and the direct gathers — every planes-per-wave form (8 / 4 / 2 / 1, 7 = 4 + 2 + 1),
+    fp32 and fp16, with and without the fused confidence blend: torch.equal."""
+    _, _, pers2equi, pers2equi_conf, L = _ops()
+    B, C, H, W, nrows, P = cfg
+    N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+    lay = L.LAYOUT_BNCHW
+    lib = L.load()
+
+    def run(fn, **opts):
+        for k, v in opts.items(): L.set_option(k, v)
+        lib.omni_geometry_cache_clear()
+        try:
+            return fn().clone()
+        finally:
+            for k in opts: L.set_option(k, {"p2e_walk": 1, "p2e_gather": 0}[k])
+            lib.omni_geometry_cache_clear()
+    for dt in (torch.float32, torch.float16):
+        x = torch.rand((B, N, C, P, P), device=DEV).to(dt)
+        f = lambda: pers2equi(x, (80, 80), nrows, (P, P), (H, W), None, layout=lay)
+        walk, lds, gat = run(f, p2e_walk=2), run(f, p2e_walk=0, p2e_gather=2), run(f, p2e_gather=1)
+        assert torch.equal(walk, lds) and torch.equal(walk, gat), f"{cfg} {dt}"
+        c = torch.rand((B, N, 1, P, P), device=DEV).to(dt)
+        d = (torch.rand((B, N, 1, P, P), device=DEV) * 8.0).to(dt)
+        fc = lambda: pers2equi_conf(d, c, (80, 80), nrows, (P, P), (H, W), layout=lay)
+        walk, lds, gat = run(fc, p2e_walk=2), run(fc, p2e_walk=0, p2e_gather=2), run(fc, p2e_gather=1)
+        assert torch.equal(walk, lds) and torch.equal(walk, gat), f"conf {cfg} {dt}"
+
+
 @pytest.mark.parametrize("cfg", [(8, 1, 512, 1024, 4, 256, "float32"), (2, 3, 256, 512, 6, 64, "float32"), (1, 2, 128, 256, 3, 20, "float16"),
                                  (3, 1, 64, 128, 5, 17, "float32")])
 def test_reference_layout_blend_via_planar_gives_the_same_bits(cfg):

@@ -274,6 +274,16 @@ int omni_depth_metrics_f32(float* pred, const float* gt, const float* mask, cons
 int omni_preprocess_rgb_u8(const unsigned char* src_hwc, float* dst_chw, int B, int Hs, int Ws, int H, int W, omni_stream_t stream);
 int omni_preprocess_depth_u16(const unsigned short* src, float* depth, unsigned char* mask, int B, int Hs, int Ws, int H, int W,
                               float min_depth, float max_depth, omni_stream_t stream);
+/* PNG decoding on the host (csrc/omni_png.hip; no GPU involved) — the two decode calls of dataset_loader_stanford.py:
+ *   :85 cv2.imread(path)      -> kind 0: uint8 [H,W,3] in B,G,R order (alpha dropped, gray replicated, 16-bit samples >> 8)
+ *   :96 cv2.imread(path, -1)  -> kind 1: the file's own samples, single-channel gray only: uint8 or uint16 (host byte order) [H,W]
+ * `data` is the file's bytes; omni_png_info reads the header only.  Colour types 0/2/3/4/6 at 8 bits, 0/2/4/6 at 16 bits, not interlaced;
+ * anything else returns OMNI_ERR_UNSUPPORTED, a damaged stream (signature, chunk CRC, zlib, size) OMNI_ERR_INVALID.
+ * omni_png_decode_batch decodes n files of one size on `threads` host threads (0: one per hardware thread) — the loader's worker pool
+ * (test.py:90-97 uses 8 DataLoader workers); dsts[i] may point into pinned memory so that the H2D copy needs no staging. */
+int omni_png_info(const void* data, size_t nbytes, int* width, int* height, int* bit_depth, int* color_type);
+int omni_png_decode(const void* data, size_t nbytes, void* dst, int H, int W, int kind);
+int omni_png_decode_batch(const void* const* datas, const size_t* nbytes, void* const* dsts, int n, int H, int W, int kind, int threads);
 /* Reverse-Huber loss of supervision/direct.py:3-18 (train_erp_depth.py:267): *loss = mean_b(sum(loss * mask * weights)_b / sum(mask)_b)
  * with c = max|gt - pred| / 5 evaluated on the device.  `workspace` (omni_berhu_workspace_bytes(B) bytes) carries c and the
  * per-item counts to omni_berhu_grad_f32, which writes dloss/dpred * (*grad_out). */

@@ -36,6 +36,7 @@ EXPORTS = [
     "omni_stem_sh", "omni_stem_sh_f16x3", "omni_maxpool3x3s2_sh", "omni_upsample_bilinear_sh", "omni_add_hw_sh", "omni_add_period_sh", "omni_layernorm512_sh", "omni_attention_qkv_sh",
     "omni_conv2d_splitk_plan", "omni_conv2d_nhwc_f32_ws",
     "omni_masked_median_f32", "omni_depth_metrics_f32",
+    "omni_png_info", "omni_png_decode", "omni_png_decode_batch",
     "omni_preprocess_rgb_u8", "omni_preprocess_depth_u16", "omni_berhu_workspace_bytes", "omni_berhu_loss_f32", "omni_berhu_grad_f32",
     "omni_pointcloud_ply_f32",
 ]
@@ -85,9 +86,14 @@ def get_option(name):
     return v.value
 
 
+CALL_LOG = None          # tools/fwd.py --labels: a list that receives the label of every library call (profiles/ label their kernel rows with it)
+
+
 def check(status, what=""):
     """Map C-ABI status codes to the exceptions the Python boundary promises
     (SURVEY.md §8b 'Errors'): ValueError for bad arguments, RuntimeError for HIP errors."""
+    if CALL_LOG is not None:
+        CALL_LOG.append(what)
     if status == OMNI_OK:
         return
     msg = load().omni_last_error().decode(errors="replace")

@@ -101,6 +101,7 @@ struct ShConvArgs {
     int res_f32;                             // residual is plain fp32 NHWC instead of SH
     int dbg;                                 // debug build only (OMNI_CONV_DBG): 4 = skip the epilogue
     int noxcd;                               // 1: identity block order (tuning, OMNI_CONV_NOXCD)
+    int wt_major;                            // 1: an XCD's contiguous block range walks tile_m fastest — it owns a range of OUTPUT-CHANNEL tiles and touches only their weights (conv_sh_kernel)
     int epi_lds;                             // 1: SH epilogues through an LDS transposition (16-byte pieces), OMNI_CONV_EPI_LDS
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
     const float* post; unsigned post_rows;   // fp32 [post_rows][Cout] added AFTER the activation, row index modulo post_rows (layer1 + point_feat), or null
@@ -262,8 +263,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     const int ntn = a.Cout / BN;
     // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous range of (tile_m, tile_n) so that the
     // blocks sharing an A row tile (and neighbouring pixels) share one L2
+    // (wt_major — the WEIGHTS are the larger operand: layer4's 9.4 MB against 4.7 MB of pixels, the transformer's matrices against 144 token
+    //  rows — an XCD gets a range of output-channel tiles instead and fetches 1/8 of the weights rather than all of them; same tiles, same bits)
     const unsigned lb = a.noxcd ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = lb / ntn, tile_n = lb % ntn;
+    const int ntm = (a.rows + BM - 1) / BM;
+    const int tile_m = a.wt_major ? (int)(lb % (unsigned)ntm) : (int)(lb / (unsigned)ntn), tile_n = a.wt_major ? (int)(lb / (unsigned)ntm) : (int)(lb % (unsigned)ntn);
     const int row0 = tile_m * BM, col0 = tile_n * BN;
     const int G1 = a.C1 >> 5, G2 = a.C2 >> 5, G = G1 + G2;
     const int ksteps = a.KH * a.KW * G;
@@ -1421,7 +1425,7 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: bad shape (kernels up to 3x3)");
     ShConvArgs a;
     a.src1 = src1; a.src2 = src2; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = dst_sh; a.res_f32 = (fmt >> 1) & 1;
-    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.epi_lds = omni_options().conv_epi_lds && !(fmt & 4);   // (fmt bit 2, one panorama: the extra barrier and LDS round trip cost more than the wider stores save)
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.wt_major = 0; a.epi_lds = omni_options().conv_epi_lds && !(fmt & 4);   // (fmt bit 2, one panorama: the extra barrier and LDS round trip cost more than the wider stores save)
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_CONV_DBG");
 #endif
@@ -1440,6 +1444,10 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
     a.splitk = S > 1 ? S : 1; a.ws = ws;
+    // block order of conv_sh_kernel: weight-stationary per XCD where the weight matrix is larger than the activation tensor(s) (option conv_wt_major:
+    // 1 auto | 0 never | 2 always)
+    a.wt_major = omni_options().conv_wt_major == 2 || (omni_options().conv_wt_major == 1 &&
+                 (long long)Cout * ksteps * 128 > (long long)M * H * W * (C1 + C2) * 4) ? 1 : 0;
     a.post = post; a.post_rows = 1;
     if (post) {
         if (Cout <= 0 || post_elems == 0 || post_elems % (size_t)Cout || post_elems / (size_t)Cout > 0x7fffffffull)
@@ -1525,7 +1533,7 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv3x3_up2_sh: tensor too large for 32-bit indices");
     ShConvArgs a;
     a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = dst; a.dst_sh = fmt & 1; a.res_f32 = 0;
-    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.epi_lds = omni_options().conv_epi_lds && !(fmt & 4);   // (fmt bit 2, one panorama: the extra barrier and LDS round trip cost more than the wider stores save)
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.wt_major = 0; a.epi_lds = omni_options().conv_epi_lds && !(fmt & 4);   // (fmt bit 2, one panorama: the extra barrier and LDS round trip cost more than the wider stores save)
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_CONV_DBG");
 #endif

@@ -29,6 +29,7 @@ const OptName kOpts[] = {
     {"conv_img", "OMNI_CONV_IMG", &OmniOptions::conv_img, 1},
     {"conv_nodeep", "OMNI_CONV_NODEEP", &OmniOptions::conv_nodeep, 0},
     {"conv_noxcd", "OMNI_CONV_NOXCD", &OmniOptions::conv_noxcd, 0},
+    {"conv_wt_major", "OMNI_CONV_WT_MAJOR", &OmniOptions::conv_wt_major, 1},
     {"conv_stem_pc", "OMNI_CONV_STEM_PC", &OmniOptions::conv_stem_pc, 1},
     {"conv_epi_lds", "OMNI_CONV_EPI_LDS", &OmniOptions::conv_epi_lds, 1},
     {"conv_up2_persist", "OMNI_CONV_UP2_PERSIST", &OmniOptions::conv_up2_persist, 1},

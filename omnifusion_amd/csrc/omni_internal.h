@@ -31,6 +31,7 @@ struct OmniOptions {
     int conv_img;         // OMNI_CONV_IMG       1 (default): 3x3 stride-1 convolutions of 16-pixel-wide images on the halo kernel (bands of whole rows) when the launch has >= 256 blocks and no split-K | 2: 8-wide too | 0: im2col tiles
     int conv_nodeep;      // OMNI_CONV_NODEEP    1: 3 pipeline stages even for single-round launches
     int conv_noxcd;       // OMNI_CONV_NOXCD     1: identity block order (no XCD-aware remap)
+    int conv_wt_major;    // OMNI_CONV_WT_MAJOR  block order of the tile kernel: 1 (default) weight-stationary per XCD where the weights are the larger operand | 0 never | 2 always
     int conv_stem_pc;     // OMNI_CONV_STEM_PC   1 (default): the stem with producer / consumer waves (8 waves, two image buffers: +2 % one forward at a time, nothing pipelined) | 0: 4 waves
     int conv_epi_lds;     // OMNI_CONV_EPI_LDS   1 (default): split-half outputs of the convolution kernels leave through an LDS transposition, 16 bytes per lane | 0: 8 bytes per lane straight from the accumulators
     int conv_up2_persist; // OMNI_CONV_UP2_PERSIST 1 (default): conv3x3(up2(x)) with 32 -> 32 channels (de_conv4_0) on the persistent kernel with resident weights | 0: the halo kernel

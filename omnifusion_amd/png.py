@@ -1,0 +1,106 @@
+"""PNG decoding for the host input pipeline — the two `cv2.imread` calls of /root/reference/dataset_loader_stanford.py (:85 RGB panorama,
+:96 16-bit depth map) on a pool of host threads, straight into pinned memory (csrc/omni_png.hip; inflate is zlib's, the rest is ours).
+
+    rgb_u8  = imread(path)                 # uint8 [H,W,3], B G R order          == cv2.imread(path)
+    depth   = imread(path, unchanged=True) # uint16 [H,W] (or uint8)             == cv2.imread(path, -1) of a gray file
+    frames  = decode_batch(list_of_paths_or_bytes, pinned=True)                  # uint8 [n,H,W,3]: what DeviceFeeder takes
+
+No GPU is involved; the arrays feed `omnifusion_amd.data.DeviceFeeder` / `preprocess_rgb` / `preprocess_depth`.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _bytes_of(src):
+    if isinstance(src, (bytes, bytearray, memoryview)):
+        return bytes(src)
+    with open(src, "rb") as fh:
+        return fh.read()
+
+
+def png_info(src):
+    """(height, width, bit_depth, colour_type) from the header"""
+    data = _bytes_of(src)
+    w, h, d, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.load().omni_png_info(data, ctypes.c_size_t(len(data)), ctypes.byref(w), ctypes.byref(h), ctypes.byref(d), ctypes.byref(c)), "png_info")
+    return h.value, w.value, d.value, c.value
+
+
+def imread(src, unchanged=False):
+    """cv2.imread(src) (BGR uint8 [H,W,3]) or, unchanged=True, cv2.imread(src, -1) of a single-channel file (uint8 / uint16 [H,W])."""
+    data = _bytes_of(src)
+    H, W, depth, ctype = png_info(data)
+    if unchanged:
+        out = np.empty((H, W), np.uint16 if depth == 16 else np.uint8)
+    else:
+        out = np.empty((H, W, 3), np.uint8)
+    _lib.check(_lib.load().omni_png_decode(data, ctypes.c_size_t(len(data)), out.ctypes.data_as(ctypes.c_void_p), H, W, 1 if unchanged else 0), "png_decode")
+    return out
+
+
+def decode_batch(srcs, unchanged=False, pinned=False, threads=0, out=None):
+    """n PNG files of ONE size -> torch tensor uint8 [n,H,W,3] (or [n,H,W] uint8 / int16-stored uint16 when unchanged=True), decoded on
+    `threads` host threads (0: all).  pinned=True allocates page-locked memory: `DeviceFeeder` then copies it to the device without staging."""
+    datas = [_bytes_of(s) for s in srcs]
+    n = len(datas)
+    if n == 0:
+        raise ValueError("decode_batch: no files")
+    H, W, depth, ctype = png_info(datas[0])
+    if unchanged:
+        shape, dt = (n, H, W), (torch.int16 if depth == 16 else torch.uint8)       # (torch has no uint16 arithmetic: preprocess_depth reinterprets)
+    else:
+        shape, dt = (n, H, W, 3), torch.uint8
+    if out is None:
+        out = torch.empty(shape, dtype=dt, pin_memory=bool(pinned and torch.cuda.is_available()))
+    elif tuple(out.shape) != shape or out.dtype != dt or out.is_cuda or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous host tensor {shape} of {dt}")
+    per = out[0].numel() * out.element_size()
+    ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(d), ctypes.c_void_p) for d in datas])
+    sizes = (ctypes.c_size_t * n)(*[len(d) for d in datas])
+    dsts = (ctypes.c_void_p * n)(*[out.data_ptr() + i * per for i in range(n)])
+    _lib.check(_lib.load().omni_png_decode_batch(ptrs, sizes, dsts, n, H, W, 1 if unchanged else 0, int(threads)), "png_decode_batch")
+    return out
+
+
+class PngBatches:
+    """Iterable of decoded batches for `DeviceFeeder`: `paths` (RGB panorama files of one size) in batches of `batch` frames, each decoded by
+    the native thread pool into its own pinned buffer, one batch AHEAD of the consumer on a background thread (the decode of batch k+1 runs
+    while batch k crosses PCIe and the network) — the role of the reference's 8 DataLoader workers (test.py:90-97) for the decode step."""
+
+    def __init__(self, paths, batch, threads=0, pinned=True, ring=3):
+        self.paths, self.batch, self.threads, self.pinned, self.ring = list(paths), int(batch), int(threads), pinned, max(2, int(ring))
+
+    def __len__(self):
+        return (len(self.paths) + self.batch - 1) // self.batch
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.ring - 1)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                for k in range(0, len(self.paths), self.batch):
+                    if stop.is_set():
+                        return
+                    q.put(decode_batch(self.paths[k:k + self.batch], pinned=self.pinned, threads=self.threads))
+                q.put(None)
+            except Exception as e:              # surfaces in the consumer
+                q.put(e)
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, Exception):
+                    raise item
+                yield item
+        finally:
+            stop.set()

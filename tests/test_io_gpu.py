@@ -137,3 +137,26 @@ def test_sharded_eval_gives_the_unsharded_averages(tmp_path):
     one = averages(base, dict(os.environ))
     two = averages(base + ["--gpus", "2"], dict(os.environ, OMNI_BENCH_DIST_BACKEND="gloo"))
     assert len(one) >= 7 and one == two, (one, two)
+
+
+def test_png_files_through_the_feeder(tmp_path):
+    """SURVEY 8f rank 2 end to end: PNG files -> native decode on host threads into pinned memory (omnifusion_amd/png.py) -> DeviceFeeder
+    (async H2D) -> /255 + HWC->CHW on the device == the loader's arithmetic on the source frames (dataset_loader_stanford.py:54,85,92-97)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_png import encode_png
+    from omnifusion_amd import png
+    from omnifusion_amd.data import DeviceFeeder
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (64, 128, 3), dtype=np.uint8) for _ in range(10)]          # file order R,G,B
+    paths = []
+    for k, f in enumerate(frames):
+        pth = tmp_path / f"pano_{k}.png"
+        pth.write_bytes(encode_png(f, 2, 8, idat=2))
+        paths.append(str(pth))
+    got = []
+    for rgb in DeviceFeeder(png.PngBatches(paths, 4, threads=2), (64, 128), device=DEV):
+        got.append(rgb.clone())
+    got = torch.cat(got).cpu().numpy()
+    want = np.stack([f[:, :, ::-1].astype(np.float32).transpose(2, 0, 1) / 255 for f in frames])   # cv2.imread -> /255 -> CHW
+    assert got.shape == (10, 3, 64, 128) and np.abs(got - want).max() <= 1e-7

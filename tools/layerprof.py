@@ -14,12 +14,21 @@ for i in reversed(idx):
         end = nxt[0]
         break
 tot = collections.Counter()
+# optional 3rd argument: the call labels of that forward (tools/fwd.py --labels, one lane): kernel k of the sequence is call k, except
+# that a split-K reduce (and a one-time weight re-pack) belongs to the call in front of it
+labels = [l.strip() for l in open(sys.argv[3])] if len(sys.argv) > 3 else None
+li = (labels.index("equi2pers") - 1) if labels and "equi2pers" in labels else -1
 for r in rows[start:end + 1]:
     n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])[:70]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot[n] += d
+    lab = ""
+    if labels is not None:
+        if not ("splitk_reduce" in n or "gemm_rows_pack" in n):
+            li += 1
+        lab = (labels[li] if 0 <= li < len(labels) else "?") + ("  (split-K reduce)" if "splitk_reduce" in n else "")
     if len(sys.argv) > 2:
-        print(f"{n:72s} grid={r['Grid_Size_X']:>9s} {d:8.1f}")
+        print(f"{lab:34s} {n[:58]:58s} grid={r['Grid_Size_X']:>9s} {d:8.1f}")
 print("---- totals (us)")
 for n, d in tot.most_common():
     print(f"{n:72s} {d:8.1f}")

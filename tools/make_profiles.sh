@@ -11,10 +11,10 @@ tools/prof_bench.sh $tag > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 for b in 8 1; do
   d=$O/prof_${tag}_b$b; rm -rf $d; mkdir -p $d
-  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $d -o l -- python $R/tools/fwd.py --batch $b --steps 6 > $d.log 2>&1
-  { echo "# kernel sequence of ONE forward of the single-pass model at $b panorama(s) per GPU (512x1024, 18 x 128^2 patches; two half-batch streams when >= 4):";
-    echo "# rocprofv3 --kernel-trace -- python tools/fwd.py --batch $b --steps 6, last forward; columns: kernel, grid (threads), duration us";
-    python $R/tools/layerprof.py $(find $d -name "l_kernel_trace.csv" | head -1) v; } > $O/${tag}_layers_b$b.txt
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $d -o l -- python $R/tools/fwd.py --batch $b --steps 6 --labels $d/labels.txt > $d.log 2>&1
+  { echo "# kernel sequence of ONE forward of the single-pass model at $b panorama(s) per GPU (512x1024, 18 x 128^2 patches), ONE lane (the whole batch per kernel, as in the pipelined steady state), each kernel alone on the GPU:";
+    echo "# rocprofv3 --kernel-trace -- python tools/fwd.py --batch $b --steps 6 --labels ..., last forward; columns: library call (layer), kernel, grid (threads), duration us";
+    python $R/tools/layerprof.py $(find $d -name "l_kernel_trace.csv" | head -1) v $d/labels.txt; } > $O/${tag}_layers_b$b.txt
 done
 cd $R
 { echo "# resample pair, per shape: tools/kbench.py (HIP events on the launch stream, 20 launches each); algorithmic bytes = B*C*(H*W + P*P*N)*s per operator (SURVEY 8d)";

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void e2p_lds_kernel(E2PArgs a, int tiles_x, in
 // built once per handle from the same sampling coordinates).  The stage loop is instantiated per NJ = pieces per box, so every
 // wait count and piece loop is a compile-time constant.  Tiles whose box exceeds the slot (the pole inside or next to the
 // tile) are listed per geometry and handled by extra blocks of the same launch with direct gathers, one per (tile, batch item).
-constexpr int E2B_NPX = 4;                      // samples per lane
+constexpr int E2B_NPX = 4;                      // samples per lane of the 8 x 32 tile (the kernels take NPX = 4 | 2 as a template parameter: 8 x 32 | 4 x 32 samples)
 constexpr int E2B_NJMAX = 8;                    // 1-KiB DMA pieces per box at most
 constexpr int E2B_RING_KB = 12;                 // LDS ring per wave (13 waves per CU by LDS; NJ <= 3: 4 slots, <= 6: 2 slots, else 1)
 
@@ -550,7 +550,7 @@ __device__ __forceinline__ void e2b_xy(const E2PArgs& a, int n, int h, int w, fl
 // the tile is E2B_TH = 8 rows x E2B_TW = 32 columns of samples, 4 per lane; every lane stores 4 adjacent samples of ONE row: one 16-byte
 // (fp16: 8-byte) store per lane and plane.  Two lane -> sample maps (e2p_box_kernel's ROWMAP); for the second one the 4x4 block (4 rows x 4
 // columns) held by each quad of lanes is transposed with DPP moves before the store.
-constexpr int E2B_TH = 8, E2B_TW = 32;
+constexpr int E2B_TW = 32;                       // (tile height: 2 NPX = 8 or 4 sample rows, a template parameter)
 
 __device__ __forceinline__ float e2b_dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float e2b_dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
@@ -572,18 +572,31 @@ __device__ __forceinline__ void e2b_quad_transpose(float (&r)[4], int lane)
     }
 }
 
+// the 4 x 32 tile (NPX = 2): lane l holds (row l/32, column l%32) and (row l/32 + 2, same column); after the exchange with lane l ^ 1 an even lane
+// holds its first row's columns (c, c+1), an odd lane its second row's columns (c-1, c): two adjacent samples of one row per lane
+__device__ __forceinline__ void e2b_pair_transpose(float (&r)[2], int lane)
+{
+    const bool odd = lane & 1;
+    const float y = e2b_dpp_xor1(odd ? r[0] : r[1]);
+    r[0] = odd ? y : r[0];
+    r[1] = odd ? r[1] : y;
+}
+__device__ __forceinline__ void e2b_transpose(float (&r)[4], int lane) { e2b_quad_transpose(r, lane); }
+__device__ __forceinline__ void e2b_transpose(float (&r)[2], int lane) { e2b_pair_transpose(r, lane); }
+
+template <int NPX>
 __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __restrict__ ent, int tiles_x, int tiles_pp, int ntiles, int epc,
                                                         int cap_chunks, int odd_pitch, int* __restrict__ stats)
 {
     const int wid = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (wid >= ntiles) return;
     const int n = wid / tiles_pp, t = wid - n * tiles_pp;
-    const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
+    const int th0 = (t / tiles_x) * (2 * NPX), tw0 = (t % tiles_x) * E2B_TW;
     const int w = min(tw0 + (lane & 31), a.pw - 1);
     const int W = a.W, H = a.H, half = W >> 1;
-    int x0[E2B_NPX], ymin = 0x7fffffff, ymax = -1;
+    int x0[NPX], ymin = 0x7fffffff, ymax = -1;
 #pragma unroll
-    for (int k = 0; k < E2B_NPX; ++k) {
+    for (int k = 0; k < NPX; ++k) {
         const int h = min(th0 + (lane >> 5) + 2 * k, a.ph - 1);
         float ix, iy;
         e2b_xy(a, n, h, w, ix, iy);
@@ -594,7 +607,7 @@ __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __rest
     const int xc = __shfl(x0[0], 0);
     int dmin = 0x7fffffff, dmax = -0x7fffffff;
 #pragma unroll
-    for (int k = 0; k < E2B_NPX; ++k) {
+    for (int k = 0; k < NPX; ++k) {
         int d = x0[k] - xc;
         if (d >= half) d -= W;
         if (d < -half) d += W;
@@ -623,6 +636,13 @@ __global__ __launch_bounds__(256) void e2b_tiles_kernel(E2PArgs a, uint2* __rest
 // NPX results of one lane -> NPX adjacent elements, one store
 template <typename T> struct E2BStore4;
 template <> struct E2BStore4<float> {
+    static __device__ __forceinline__ void st(float* p, const float (&r)[2]) { *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]); }
+    static __device__ __forceinline__ void st_nt(float* p, const float (&r)[2])
+    {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f v = {r[0], r[1]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(p));
+    }
     static __device__ __forceinline__ void st(float* p, const float (&r)[4]) { *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]); }
     // non-temporal form: the output is never re-read by this kernel (the ERP boxes are), and at 16 panoramas — 327 MB per launch, more than
     // the 256-MB memory-side cache — it is what keeps the launch at the 8-panorama rate (106 -> 64-74 us; 8 panoramas 38.5 -> 36.8).  sc1
@@ -635,6 +655,10 @@ template <> struct E2BStore4<float> {
     }
 };
 template <> struct E2BStore4<__half> {
+    static __device__ __forceinline__ void st(__half* p, const float (&r)[2])
+    { __half2 v = __floats2half2_rn(r[0], r[1]); *reinterpret_cast<unsigned*>(p) = *reinterpret_cast<unsigned*>(&v); }
+    static __device__ __forceinline__ void st_nt(__half* p, const float (&r)[2])
+    { __half2 v = __floats2half2_rn(r[0], r[1]); __builtin_nontemporal_store(*reinterpret_cast<unsigned*>(&v), reinterpret_cast<unsigned*>(p)); }
     static __device__ __forceinline__ void st(__half* p, const float (&r)[4])
     { __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]); uint2 v; v.x = *reinterpret_cast<unsigned*>(&lo); v.y = *reinterpret_cast<unsigned*>(&hi); *reinterpret_cast<uint2*>(p) = v; }
     static __device__ __forceinline__ void st_nt(__half* p, const float (&r)[4])
@@ -646,11 +670,11 @@ template <> struct E2BStore4<__half> {
     }
 };
 
-template <typename T, int NBMAX, bool ROWMAP>
+template <typename T, int NBMAX, bool ROWMAP, int NPX = E2B_NPX>
 __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* __restrict__ work, int tiles_x, int tiles_pp, unsigned tensor_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char e2b_smem[];        // the ONLY LDS object of this kernel
-    constexpr int EPC = 16 / (int)sizeof(T), NPX = E2B_NPX;
+    constexpr int EPC = 16 / (int)sizeof(T), TILE_H = 2 * NPX, LPR = E2B_TW / NPX;   // tile rows; lanes per tile row of the direct lane map
     const int lane = threadIdx.x;
     long long tr0 = 0, tr1 = 0;
     if (OMNI_DBG(a, 16)) tr0 = wall_clock64();
@@ -664,13 +688,13 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
     const int wid = (int)(wk.x & 0x7fffffffu);
     const uint2 e = make_uint2(wk.z, wk.w);
     const int n = wid / tiles_pp, t = wid - n * tiles_pp;
-    const int th0 = (t / tiles_x) * E2B_TH, tw0 = (t % tiles_x) * E2B_TW;
+    const int th0 = (t / tiles_x) * TILE_H, tw0 = (t % tiles_x) * E2B_TW;
     const int W = a.W, H = a.H;
     // lane -> samples.  ROWMAP (2-byte elements): lane computes (row lane/32 + 2k, column lane%32) — a half-wave, the conflict group of
     // ds_read2_b32, reads the taps of 32 consecutive samples of one row — and the results are transposed inside each quad before the
     // store.  Otherwise (4-byte elements) lane computes the 4 adjacent samples (row lane/8, columns 4 (lane%8) + k) it stores; measured
     // per shape: fp32 22 vs 27 us at P = 128 and equal at P = 256 in favour of the direct form, fp16 cfg5 72 vs 126 us in favour of ROWMAP.
-    const int w = ROWMAP ? tw0 + (lane & 31) : tw0 + 4 * (lane & 7), hb = ROWMAP ? th0 + (lane >> 5) : th0 + (lane >> 3);
+    const int w = ROWMAP ? tw0 + (lane & 31) : tw0 + NPX * (lane % LPR), hb = ROWMAP ? th0 + (lane >> 5) : th0 + lane / LPR;
     const int xs4 = (int)(e.y & 0xffff), ymin = (int)(e.y >> 16), bw4 = (int)(e.x & 4095), bh = (int)((e.x >> 12) & 4095);
     const int pitch = bw4 * EPC;
 
@@ -760,10 +784,10 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
         r1[k] = (y1 - ymin) * pitch + c0;
     }
     const size_t out_bstride = (size_t)a.tab.N * a.C * plane;
-    // ROWMAP: after the quad transpose lane l holds row hb + 2 (l % 4), columns 4 ((l % 32) / 4) .. +3 of the tile
+    // ROWMAP: after the transpose inside each group of NPX lanes, lane l holds row hb + 2 (l % NPX), columns NPX ((l % 32) / NPX) .. + NPX - 1 of the tile
     const int b0 = p_start / a.C, c0p = p_start - b0 * a.C;        // batch item / channel of my first plane
     T* out = (T*)a.pers + (size_t)b0 * out_bstride + ((size_t)n * a.C + c0p) * plane +
-             (ROWMAP ? (size_t)(hb + 2 * (lane & 3)) * a.pw + tw0 + 4 * ((lane & 31) >> 2) : (size_t)hb * a.pw + w);
+             (ROWMAP ? (size_t)(hb + 2 * (lane % NPX)) * a.pw + tw0 + NPX * ((lane & 31) / NPX) : (size_t)hb * a.pw + w);
     const size_t bskip = out_bstride - (size_t)a.C * plane;
 
     if (fb_block) {
@@ -797,7 +821,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
                     float r[NPX];
 #pragma unroll
                     for (int k = 0; k < NPX; ++k) r[k] = e2p_blend(v[u][k][0], v[u][k][1], v[u][k][2], v[u][k][3], w00[k], w01[k], w10[k], w11[k]);
-                    if (ROWMAP) e2b_quad_transpose(r, lane);
+                    if (ROWMAP) e2b_transpose(r, lane);
                     E2BStore4<T>::st(dstb, r);
                     dstb += plane;
                     if (++cc == a.C) { cc = 0; dstb += bskip; }
@@ -834,7 +858,7 @@ __global__ __launch_bounds__(64, 4) void e2p_box_kernel(E2PArgs a, const uint4* 
                 E2BPair<T>::ld(box, r1[k], b0, b1);
                 r[k] = e2p_blend(a0, a1, b0, b1, w00[k], w01[k], w10[k], w11[k]);
             }
-            if (ROWMAP) e2b_quad_transpose(r, lane);
+            if (ROWMAP) e2b_transpose(r, lane);
         };
         auto store = [&](const float (&r)[NPX]) {
             if (OMNI_DBG(a, 128)) { if (lane == 0) E2BStore4<T>::st_nt(dst, r); }      // (debug bit 128: the store instruction with ONE active lane — its acknowledge without its bytes)
@@ -1090,21 +1114,28 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
     int cap_kb = omni_options().e2p_slot_kb;
     if (cap_kb < 1) cap_kb = 1;
     if (cap_kb > E2B_NJMAX) cap_kb = E2B_NJMAX;
-    for (int e = 0; e < 2; ++e) {
+    // tile height: 8 x 32 samples (option e2p_tile_h: 4 = 4 x 32 tiles, 2 = 4 x 32 where more than 1 tile in 8 of the 8-row tiling would take the gather
+    // path — a sample spans several ERP pixels: 128^2 patches on 512 x 1024, 256^2 on 1024 x 2048, 512^2 on 2048 x 4096)
+    auto build_one = [&](int e, int th) -> int {
         auto& tt = g->e2p_boxes[e];
-        tt.tw = E2B_TW; tt.th = E2B_TH;
+        if (tt.ent) (void)hipFree(tt.ent);
+        if (tt.fb) (void)hipFree(tt.fb);
+        if (tt.order) (void)hipFree(tt.order);
+        tt.ent = nullptr; tt.fb = nullptr; tt.order = nullptr; tt.norder = 0; tt.nfb = 0; tt.h_fb.clear();
+        tt.tw = E2B_TW; tt.th = th;
         tt.ok = 0;
-        if (g->pw % tt.tw != 0 || g->ph % tt.th != 0 || g->W < 2) continue;      // whole tiles only (16-byte stores, static store count per stage)
+        if (g->pw % tt.tw != 0 || g->ph % tt.th != 0 || g->W < 2) return OMNI_OK;      // whole tiles only (16-byte stores, static store count per stage)
         tt.tx = g->pw / tt.tw; tt.ty = g->ph / tt.th;
         const long long ntiles = (long long)g->N * tt.tx * tt.ty;
-        if (ntiles >= (1ll << 24)) continue;
+        if (ntiles >= (1ll << 24)) return OMNI_OK;
         const int epc = e ? 8 : 4;
         int* dstats = nullptr;
         OMNI_HIP(hipMalloc((void**)&dstats, sizeof(int) * (size_t)(2 + ntiles)));
         if (hipMalloc((void**)&tt.ent, sizeof(uint2) * (size_t)ntiles) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_e2p_build_boxes: out of memory"); }
         (void)hipMemsetAsync(dstats, 0, 2 * sizeof(int), stream);
         const unsigned nb = (unsigned)((ntiles + 3) / 4);
-        hipLaunchKernelGGL(e2b_tiles_kernel, dim3(nb), dim3(256), 0, stream, a, tt.ent, tt.tx, tt.tx * tt.ty, (int)ntiles, epc, cap_kb * 64, e /* odd pitch: fp16 */, dstats);
+        if (tt.th == 8) hipLaunchKernelGGL(e2b_tiles_kernel<4>, dim3(nb), dim3(256), 0, stream, a, tt.ent, tt.tx, tt.tx * tt.ty, (int)ntiles, epc, cap_kb * 64, e /* odd pitch: fp16 */, dstats);
+        else            hipLaunchKernelGGL(e2b_tiles_kernel<2>, dim3(nb), dim3(256), 0, stream, a, tt.ent, tt.tx, tt.tx * tt.ty, (int)ntiles, epc, cap_kb * 64, e, dstats);
         std::vector<int> hs((size_t)(2 + ntiles));
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs.data(), dstats, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_e2p_build_boxes: kernel failed"); }
@@ -1162,6 +1193,20 @@ int omni_e2p_build_boxes(omni_geometry* g, hipStream_t stream)
             fprintf(stderr, "[omni] equi2pers %dx%d patches on %dx%d, %d-byte elements, %dx%d sample tiles: largest staged tap box %d chunks, "
                             "%d of %lld tiles take the gather path (box > %d KiB)\n", g->ph, g->pw, g->H, g->W, 16 / epc, tt.th, tt.tw, tt.max_chunks,
                     tt.nfb, ntiles, cap_kb);
+        return OMNI_OK;
+    };
+    for (int e = 0; e < 2; ++e) {
+        const int opt = omni_options().e2p_tile_h;
+        int rc = build_one(e, opt == 4 ? 4 : 8);
+        if (rc != OMNI_OK) return rc;
+        auto& tt = g->e2p_boxes[e];
+        // (round 4: 4 x 32 tiles where more than 1 tile in 8 would gather — option e2p_tile_h = 2 — measured: 18 x 128^2 patches at 8 panoramas
+        //  24.4 -> 20.9 us, but every single-panorama shape LOSES (cfg 3 26.5 -> 28.8 us, cfg 5 fp16 72.9 -> 95.9: twice the blocks, each with its
+        //  set-up, and only 1-3 planes to amortise it over; the gather share only falls from 37 % to 21 %: the boxes are WIDE, not tall) — not the default)
+        if (opt == 2 && tt.ok && (long long)tt.nfb * 8 > (long long)g->N * tt.tx * tt.ty && g->ph % 4 == 0) {
+            rc = build_one(e, 4);
+            if (rc != OMNI_OK) return rc;
+        }
     }
     return OMNI_OK;
 }
@@ -1278,8 +1323,10 @@ int launch_e2b_nb(const E2PArgs& a, const omni_geometry* g, int B, int C, size_t
     const int njmax = (tt.max_chunks + 63) / 64;
     const size_t lds = e2b_lds_bytes(tt.max_chunks, NBMAX);
     (void)njmax;
-    hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2>), dim3(wk.nblocks), dim3(64), lds, stream, a, (const uint4*)wk.dev, tt.tx, tt.tx * tt.ty,
-                       (unsigned)tensor_bytes);
+    if (tt.th == 8) hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2, 4>), dim3(wk.nblocks), dim3(64), lds, stream, a, (const uint4*)wk.dev, tt.tx, tt.tx * tt.ty,
+                                       (unsigned)tensor_bytes);
+    else            hipLaunchKernelGGL((e2p_box_kernel<T, NBMAX, sizeof(T) == 2, 2>), dim3(wk.nblocks), dim3(64), lds, stream, a, (const uint4*)wk.dev, tt.tx, tt.tx * tt.ty,
+                                       (unsigned)tensor_bytes);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

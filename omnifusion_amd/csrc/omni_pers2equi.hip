@@ -696,16 +696,18 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
         }
     };
 
-    auto run = [&]<int NJ>(std::integral_constant<int, NJ>) {
+    // byte offset of my chunk of piece q from the box origin + the box origin (wave-uniform) of the patch the NEXT refill reads: the current
+    // patch for the iterations whose refill stages lie inside it, the following patch from iteration JS on (ONE set of registers: U | NB | PL,
+    // so an iteration refills entirely from one patch).  Only the part of the program that depends on NJ — the DMA pieces, the stage loop and its
+    // counted waits — is instantiated per NJ (the tap geometry, ~350 instructions, exists twice in the kernel, not twice per NJ: 45 -> ~25 KB of
+    // code; the two CUs that share an instruction cache run tiles of every NJ at once).
+    unsigned gc[P2W_NJMAX], base_c = 0;
+    auto run = [&]<int NJ, int PHASE>(std::integral_constant<int, NJ>, std::integral_constant<int, PHASE>, const uint4& nrec) {
         constexpr int NB = p2w_nb(NJ * M, PL), U = p2w_u(NB, PL), ITERS = PL / U;
         constexpr unsigned slot_bytes = NJ * M * 1024u;
         static_assert(PL % NB == 0 && NB % U == 0, "a stage's ring slot must be a compile-time constant");
-        // byte offset of my chunk of piece q from the box origin + the box origin (wave-uniform) of the patch the NEXT refill reads: the current
-        // patch for the iterations whose refill stages lie inside it, the following patch from iteration JS on (ONE set of registers: U | NB | PL,
-        // so an iteration refills entirely from one patch)
-        unsigned gc[NJ], base_c = 0;
         constexpr int JS = (PL - NB) / U;                          // first iteration whose refills belong to the next patch
-        auto dma_params = [&](const uint4& ra, unsigned (&g)[NJ], unsigned& base) {
+        auto dma_params = [&](const uint4& ra, unsigned (&g)[P2W_NJMAX], unsigned& base) {
             const unsigned e0 = ra.x, e1 = ra.y;
             const int n = e0 & 63, bw4 = (e0 >> 6) & 1023, xa = e1 & 0xffff, ymin = e1 >> 16;
             const int nchunk = bw4 * (int)((e0 >> 16) & 1023);
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
                 g[q] = qc < nchunk ? (unsigned)rr * sYb + (unsigned)(qc - rr * bw4) * 16u : 0x80000000u;   // past the end (of THIS patch's box): zeros
             }
         };
-        auto issue = [&](const unsigned (&g)[NJ], unsigned base, int plane, int slot_i) {
+        auto issue = [&](const unsigned (&g)[P2W_NJMAX], unsigned base, int plane, int slot_i) {
             if (OMNI_DBG(a, 4)) return;
             const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)poff_l, plane) + base;
             unsigned char* dst = ring + (unsigned)slot_i * slot_bytes;
@@ -775,30 +777,34 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
                 }()), ...);
             }(std::make_integer_sequence<int, ITERS>());
         };
-        // ---- head of the stream: the first NB stages of patch 0 go out, its taps are evaluated while they travel
-        dma_params(ea, gc, base_c);
+        if constexpr (PHASE == 0) {                               // head of the stream: the first NB stages of patch 0 go out
+            dma_params(nrec, gc, base_c);
 #pragma unroll
-        for (int d = 0; d < NB; ++d) issue(gc, base_c, d, d);
-        taps(ea, eb);
-        for (int c = 0; c < ncand; ++c) {
-            const bool last = c + 1 == ncand;
-            const uint4 na = sl[2 * (c + 2)], nb4 = sl[2 * (c + 2) + 1];    // record of patch c + 1 (a zero record past the list)
-            if (!last) {
-                body(std::bool_constant<false>(), na);
-                taps(na, nb4);                                      // ... under the flight time of its own first boxes
-            } else {
-                body(std::bool_constant<true>(), na);
-            }
-        }
+            for (int d = 0; d < NB; ++d) issue(gc, base_c, d, d);
+        } else if constexpr (PHASE == 1) body(std::bool_constant<false>(), nrec);
+        else body(std::bool_constant<true>(), nrec);
     };
     // (boxes of up to P2W_NJMAX KiB: every BASELINE shape is 1-3; a geometry with larger boxes — patches much finer than the ERP — stays on p2e_lds_kernel)
-    switch (njt) {
-    case 1: run(std::integral_constant<int, 1>()); break;
-    case 2: run(std::integral_constant<int, 2>()); break;
-    case 3: run(std::integral_constant<int, 3>()); break;
-    case 4: run(std::integral_constant<int, 4>()); break;
-    case 5: run(std::integral_constant<int, 5>()); break;
-    default: run(std::integral_constant<int, P2W_NJMAX>()); break;
+    auto with_nj = [&]<int PHASE>(std::integral_constant<int, PHASE> ph, const uint4& nrec) {
+        switch (njt) {
+        case 1: run(std::integral_constant<int, 1>(), ph, nrec); break;
+        case 2: run(std::integral_constant<int, 2>(), ph, nrec); break;
+        case 3: run(std::integral_constant<int, 3>(), ph, nrec); break;
+        case 4: run(std::integral_constant<int, 4>(), ph, nrec); break;
+        case 5: run(std::integral_constant<int, 5>(), ph, nrec); break;
+        default: run(std::integral_constant<int, P2W_NJMAX>(), ph, nrec); break;
+        }
+    };
+    with_nj(std::integral_constant<int, 0>(), ea);
+    taps(ea, eb);                                                  // ... evaluated while the first boxes travel
+    for (int c = 0; c < ncand; ++c) {
+        const uint4 na = sl[2 * (c + 2)], nb4 = sl[2 * (c + 2) + 1];        // record of patch c + 1 (a zero record past the list)
+        if (c + 1 < ncand) {
+            with_nj(std::integral_constant<int, 1>(), na);
+            taps(na, nb4);                                          // ... under the flight time of its own first boxes
+        } else {
+            with_nj(std::integral_constant<int, 2>(), na);
+        }
     }
     // ---- normalise and store (pers2equi_v3.py:192-196; K11: spherical_model.py:310-311)
     const size_t erp_plane = (size_t)a.H * a.W;

@@ -40,6 +40,7 @@ struct E2PArgs {
     const float2* ixy;         // per-geometry table of clamped sampling coordinates [N][ph][pw] (e2p_lds_kernel), or null
     long long* trace;          // debug build, OMNI_E2P_DBG bit 16: per-block time stamps (omni_debug_set_trace)
     int store_mode;            // option e2p_store: 0 plain | 1 non-temporal (default)
+    int dbg_skip_fb;           // timing experiment only (option e2p_ref_lds = 2)
     PatchTab tab;
 };
 
@@ -1013,6 +1014,202 @@ __global__ __launch_bounds__(256) void e2p_reflayout_kernel(E2PArgs a, int tiles
     }
 }
 
+// ------------------------------------------------------------------ reference output [B,C,ph,pw,N], LDS-staged (round 4)
+// The drop-in equi2pers() returns the reference's own layout (equi2pers_v3.py:112-113: N innermost).  e2p_reflayout_kernel above gathers through
+// L1 / L2 (72 us at 8 x 18 x 256^2 where the planar box kernel takes 32); planar + a transposing pass is no faster (113 MB more in each
+// direction).  Here ONE BLOCK owns a tile POSITION (8 x 32 samples) of ALL N patches: wave w stages the ERP tap boxes of its PPW patches
+// (w PPW .. w PPW + PPW - 1) by LDS-DMA exactly as e2p_box_kernel does — same per-geometry box table, same taps, same e2p_blend: same bits —,
+// parks its results in an LDS tile laid out like the destination ([row][column][patch]) and after ONE block barrier per plane the whole block
+// streams that tile out as 16-byte pieces (8 contiguous runs of 32 N elements).  The boxes of plane p+1 are in flight from the moment plane p's
+// taps have been read (one slot per patch: the barrier, the tile write and the stores are what they travel under); the output tile is double
+// buffered, so the barrier of plane p also licenses the rewrite of the tile of plane p-1.  Counted waits: a wave's queue holds, in order, the
+// pieces of its PPW boxes and the S store instructions of the previous plane — waiting for box j leaves (PPW-1) NJ + S younger operations, NJ
+// the wave's pieces per box (the largest of its patches: smaller boxes pad with out-of-range lanes).  A wave with a patch whose box does not
+// fit a slot (pole tiles) takes that patch by direct gathers and waits with vmcnt(0) throughout.
+template <typename T, int PPW, int S>
+__global__ __launch_bounds__(PPW == 1 ? 1024 : 640) void e2p_ref_kernel(E2PArgs a, const uint2* __restrict__ ent, int tiles_x, int tiles_pp, unsigned tensor_bytes,
+                                                       int slot_bytes, int planes_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char e2r_smem[];
+    constexpr int EPC = 16 / (int)sizeof(T), NPX = 4, TH = 8, TW = 32;
+    // lane -> samples: (row lane / 32 + 2 k, column lane % 32) for every element size — the results go to the [row][column][patch] tile one by
+    // one, and 32 consecutive columns of one row are N elements apart there: 16 distinct banks (N = 18).  The box kernel's direct map for 4-byte
+    // elements (4 adjacent columns per lane) puts a wave's 64 stores on FOUR banks: 2.4 us per plane, measured.
+    constexpr bool ROWMAP = true;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nthreads = (int)blockDim.x;
+    const int N = a.tab.N, W = a.W, H = a.H, ph_ = a.ph, pw_ = a.pw;
+    const float2* __restrict__ ixy = a.ixy;
+    const int t = (int)omni_xcd_remap(blockIdx.x, gridDim.x);      // an XCD owns a band of tile rows: neighbouring boxes of every patch share its L2
+    const int th0 = (t / tiles_x) * TH, tw0 = (t % tiles_x) * TW;
+    const int planes = a.B * a.C;
+    const int p_begin = (int)blockIdx.y * planes_per_block, np = min(planes, p_begin + planes_per_block) - p_begin;
+    if (np <= 0) return;
+    unsigned char* const ring = e2r_smem + (unsigned)(wave * PPW) * (unsigned)slot_bytes;
+    const int out_elems = TH * TW * N;
+    T* const otile = reinterpret_cast<T*>(e2r_smem + (unsigned)((nthreads >> 6) * PPW) * (unsigned)slot_bytes);   // [2][TH][TW][N]
+    const int w = ROWMAP ? tw0 + (lane & 31) : tw0 + 4 * (lane & 7), hb = ROWMAP ? th0 + (lane >> 5) : th0 + (lane >> 3);
+
+    // (every per-patch array below is indexed by a COMPILE-TIME j: a run-time index would put them into scratch memory)
+    auto for_j = [&](auto&& f) { [&]<int... J>(std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>()), ...); }(std::make_integer_sequence<int, PPW>()); };
+    // ---- my patches: box entries, sampling coordinates, taps
+    bool valid[PPW], fits[PPW];
+    int xs4[PPW], ymin[PPW], bw4[PPW], nchunk[PPW], pn[PPW];
+    int r0[PPW][NPX], r1[PPW][NPX], oi[PPW];                      // (oi: tile element of sample 0; sample k is OSTEP elements further)
+    int g0[PPW][NPX], g1[PPW][NPX];                                // absolute tap pairs: used by the gather path only (dead in the waves without one)
+    const int OSTEP = ROWMAP ? 2 * TW * N : N;
+    float w00[PPW][NPX], w01[PPW][NPX], w10[PPW][NPX], w11[PPW][NPX];
+    int nj = 1;
+    bool sync_mode = false;
+    for_j([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int n = wave * PPW + j;
+        pn[j] = n;
+        valid[j] = n < N;
+        fits[j] = false; xs4[j] = ymin[j] = 0; bw4[j] = 1; nchunk[j] = 0; oi[j] = 0;
+        if (!valid[j]) { sync_mode = sync_mode || PPW > 1; return; }
+        const uint2 e = ent[(size_t)n * tiles_pp + t];
+        fits[j] = (e.x >> 31) != 0;
+        xs4[j] = (int)(e.y & 0xffff); ymin[j] = (int)(e.y >> 16); bw4[j] = (int)(e.x & 4095);
+        nchunk[j] = bw4[j] * (int)((e.x >> 12) & 4095);
+        if (a.dbg_skip_fb && !fits[j]) { valid[j] = false; return; }      // (timing experiment: option e2p_ref_lds = 2 drops the pole patches — wrong results)
+        if (fits[j]) nj = max(nj, (nchunk[j] + 63) >> 6); else sync_mode = true;
+        const int pitch = bw4[j] * EPC;
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            const int hh = ROWMAP ? hb + 2 * k : hb, ww = ROWMAP ? w : w + k;
+            const float2 cxy = ixy[((size_t)n * ph_ + hh) * pw_ + ww];   // (the per-geometry coordinate table: the launch requires it)
+            const float ix = cxy.x, iy = cxy.y;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy;
+            const float tx = ix - fx, ty = iy - fy, ex = 1.0f - tx, ey = 1.0f - ty;
+            w00[j][k] = ey * ex; w01[j][k] = ey * tx; w10[j][k] = ty * ex; w11[j][k] = ty * tx;
+            const int y1 = min(y0 + 1, H - 1);
+            int c0 = x0 - xs4[j];
+            if (c0 < 0) c0 += W;
+            int sh = 0;
+            if (x0 + 1 >= W) {                                     // (see e2p_box_kernel: the pair moved one column left, the x0 weights to its second element)
+                c0 -= 1; sh = 1;
+                w01[j][k] = w00[j][k]; w00[j][k] = 0.0f; w11[j][k] = w10[j][k]; w10[j][k] = 0.0f;
+            }
+            r0[j][k] = (y0 - ymin[j]) * pitch + c0;
+            r1[j][k] = (y1 - ymin[j]) * pitch + c0;
+            g0[j][k] = y0 * W + x0 - sh; g1[j][k] = y1 * W + x0 - sh;
+            if (k == 0) oi[j] = ((hh - th0) * TW + (ww - tw0)) * N + n;      // element of the [row][column][patch] tile
+        }
+    });
+    nj = __builtin_amdgcn_readfirstlane(nj);
+    const size_t img_plane = (size_t)H * W;
+    const e2b_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.erp), (short)0, (int)tensor_bytes, 0x00020000);
+    const unsigned rowb = (unsigned)W * (unsigned)sizeof(T), planeb = (unsigned)img_plane * (unsigned)sizeof(T);
+    // output: plane p of [B,C,ph,pw,N] starts at p * ph * pw * N; row hh of my tile is the contiguous run [th0 + hh][tw0 .. tw0 + 31][0 .. N)
+    const int ppr = TW * N * (int)sizeof(T) / 16, total_pieces = TH * ppr;          // 16-byte pieces per tile row / per tile
+    const size_t out_plane = (size_t)a.ph * a.pw * N;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every set-up load has landed: only counted operations from here on
+#pragma unroll
+    for (int j = 0; j < PPW; ++j)
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) asm volatile("" ::"v"(w00[j][k]), "v"(w11[j][k]), "v"(r0[j][k]));
+
+    auto run = [&]<int NJ, bool SYNC>(std::integral_constant<int, NJ>, std::bool_constant<SYNC>) {
+        unsigned g[PPW][NJ];
+        for_j([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float rbw = __builtin_amdgcn_rcpf((float)bw4[j]);
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                const int qc = q * 64 + lane;
+                const int rr = (int)(((float)qc + 0.5f) * rbw);
+                int gx = xs4[j] + (qc - rr * bw4[j]) * EPC;
+                if (gx >= W) gx -= W;                                 // the box wraps at the seam
+                g[j][q] = (fits[j] && qc < nchunk[j]) ? (unsigned)(ymin[j] + rr) * rowb + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;
+            }
+        });
+        // planes in flight per patch: two where two boxes of NJ KiB fit the patch's slot (a plane's period is then half a memory round trip
+        // instead of a whole one: with ONE box per patch the refill issued after plane p has a single plane-time to land — measured 2.4 us per plane)
+        const int nb = (2 * NJ * 1024 <= slot_bytes) ? 2 : 1;        // (wave-uniform, a property of the launch)
+        auto issue = [&]<int j>(std::integral_constant<int, j>, int p) {
+            unsigned char* dst = ring + (unsigned)j * (unsigned)slot_bytes + (unsigned)((p & (nb - 1)) * NJ * 1024);
+            const unsigned so = (unsigned)(p_begin + p) * planeb;
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) e2b_dma16(rs, dst + q * 1024, g[j][q], so);
+        };
+        // NBC: boxes per patch in flight in the STEADY state (0: this plane waits with vmcnt(0) — the first plane, the last NB planes, SYNC waves)
+        auto plane = [&]<int NBC>(std::integral_constant<int, NBC>, int p) {
+            T* ot = otile + (size_t)(p & 1) * out_elems;
+            const bool refill = p + nb < np;
+            for_j([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (!valid[j]) return;                              // (wave-uniform)
+                float r[NPX];
+                if (fits[j]) {
+                    // steady state: behind box (j, p) the queue holds the other NBC PPW - 1 boxes in flight and the stores of the NBC planes before this one
+                    if constexpr (SYNC || NBC == 0) e2b_wait_vm<0>();
+                    else e2b_wait_vm<(NBC * PPW - 1) * NJ + NBC * S>();
+                    const unsigned char* box = ring + (unsigned)j * (unsigned)slot_bytes + (unsigned)((p & (nb - 1)) * NJ * 1024);
+#pragma unroll
+                    for (int k = 0; k < NPX; ++k) {
+                        float a0, a1, b0, b1;
+                        E2BPair<T>::ld(box, r0[j][k], a0, a1);
+                        E2BPair<T>::ld(box, r1[j][k], b0, b1);
+                        r[k] = e2p_blend(a0, a1, b0, b1, w00[j][k], w01[j][k], w10[j][k], w11[j][k]);
+                    }
+                    if (refill) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(jc, p + nb); }
+                } else {
+                    // (a pole tile: direct gathers of this plane's taps)
+                    if constexpr (SYNC) {
+                        const T* im = (const T*)a.erp + (size_t)(p_begin + p) * img_plane;
+#pragma unroll
+                        for (int k = 0; k < NPX; ++k) {
+                            float a0, a1, b0, b1;
+                            Pair<T>::ld(im + g0[j][k], a0, a1);
+                            Pair<T>::ld(im + g1[j][k], b0, b1);
+                            r[k] = e2p_blend(a0, a1, b0, b1, w00[j][k], w01[j][k], w10[j][k], w11[j][k]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NPX; ++k) r[k] = 0.0f;  // (not reached: a wave without a gather patch)
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NPX; ++k) Store<T>::st(ot + oi[j] + k * OSTEP, r[k]);
+            });
+            __syncthreads();                                        // the tile of plane p is complete (and the tile of plane p-1 has been read by everybody)
+            // the tile leaves as 16-byte pieces; EVERY wave issues exactly S store instructions (a thread past the end repeats the last piece)
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(ot);
+            unsigned char* dstp = reinterpret_cast<unsigned char*>((T*)a.pers + (size_t)(p_begin + p) * out_plane + ((size_t)th0 * a.pw + tw0) * N);
+            const size_t row_stride = (size_t)a.pw * N * sizeof(T);
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) {
+                const int piece = min((int)threadIdx.x + s2 * nthreads, total_pieces - 1);
+                const int row = piece / ppr, c16 = piece - row * ppr;
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const v4u v = *reinterpret_cast<const v4u*>(src + (size_t)piece * 16);
+                __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dstp + (size_t)row * row_stride + (size_t)c16 * 16));
+            }
+        };
+        for (int d = 0; d < nb && d < np; ++d)
+            for_j([&](auto jc) { constexpr int j = decltype(jc)::value; if (valid[j] && fits[j]) issue(jc, d); });
+        // plane 0 (no stores in the queue yet) and the last nb planes (no refills) wait for everything; the planes in between with counted waits
+        plane(std::integral_constant<int, 0>(), 0);
+        int p = 1;
+        if (nb == 2) for (; p + 2 < np; ++p) plane(std::integral_constant<int, 2>(), p);
+        else         for (; p + 1 < np; ++p) plane(std::integral_constant<int, 1>(), p);
+        for (; p < np; ++p) plane(std::integral_constant<int, 0>(), p);
+    };
+    auto with_nj = [&]<bool SYNC>(std::bool_constant<SYNC> sy) {
+        switch (nj) {
+        case 1: run(std::integral_constant<int, 1>(), sy); break;
+        case 2: run(std::integral_constant<int, 2>(), sy); break;
+        case 3: run(std::integral_constant<int, 3>(), sy); break;
+        case 4: run(std::integral_constant<int, 4>(), sy); break;
+        case 5: run(std::integral_constant<int, 5>(), sy); break;
+        default: run(std::integral_constant<int, 6>(), sy); break;
+        }
+    };
+    if (__builtin_amdgcn_readfirstlane((int)sync_mode)) with_nj(std::bool_constant<true>());
+    else with_nj(std::bool_constant<false>());
+}
+
 // ------------------------------------------------------------------ aux outputs
 // xyz[n,:,h,w] = (cos lat sin lon, cos lat cos lon, sin lat) from the UNWRAPPED lon (:13-18,115-118),
 // here without further trig:  cos lat * (sin|cos)(l0 + atan2(x,q)) = inv * (..) algebraically.
@@ -1055,6 +1252,7 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
     a.ixy = g->e2p_ixy;
     a.dbg = 0; a.trace = nullptr;
     a.store_mode = omni_options().e2p_store;
+    a.dbg_skip_fb = omni_options().e2p_ref_lds == 2;
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_E2P_DBG");
     a.trace = omni_debug_trace_buf();
@@ -1384,6 +1582,46 @@ int launch_e2p(const omni_geometry* g, const void* erp, void* pers, int B, int C
         else OMNI_FAIL(OMNI_ERR_INVALID, "bad OMNI_E2P_VAR");
 #undef E2P_LAUNCH
     } else if (layout == OMNI_LAYOUT_BCHWN) {
+        // the LDS-staged form (e2p_ref_kernel) where its block fits the CU: one wave per PPW patches, a slot per patch, two output tiles
+        {
+            const auto& bt = g->e2p_boxes[sizeof(T) == 2 ? 1 : 0];
+            const long long tensor_bytes = (long long)B * C * g->H * g->W * (long long)sizeof(T);
+            const int ppw = N <= 16 ? 1 : 2, nwv = (N + ppw - 1) / ppw;                          // (N <= 20: nrows 3 and 4; larger sets do not fit a CU's LDS)
+            const int slot_bytes = std::max(1, (bt.max_chunks + 63) / 64) * 1024;
+            const size_t lds = (size_t)nwv * ppw * slot_bytes + 2 * (size_t)8 * 32 * N * sizeof(T);
+            const int total_pieces = 8 * 32 * N * (int)sizeof(T) / 16, sst = (total_pieces + nwv * 64 - 1) / (nwv * 64);
+            if (bt.ok && bt.th == 8 && omni_options().e2p_ref_lds && !omni_options().e2p_gather && tensor_bytes < (1ll << 31) && (uintptr_t)erp % 16 == 0 &&
+                (uintptr_t)pers % 16 == 0 && lds <= 160 * 1024 && sst <= 3 && g->e2p_ixy && nwv <= (ppw == 1 ? 16 : 10)) {
+                // one block per tile position and plane range: all planes in one block where the positions alone fill the chip (18 x 256^2: 256),
+                // else plane ranges of >= 6 planes until there are about as many blocks as CUs (18 x 128^2: 64 positions)
+                const int tiles = bt.tx * bt.ty, planes = B * C;
+                int py = std::max(1, std::min(planes / 6, (omni_num_cus() + tiles - 1) / tiles));
+                const int ppb = (planes + py - 1) / py;
+                py = (planes + ppb - 1) / ppb;
+                const dim3 grid((unsigned)tiles, (unsigned)py), block((unsigned)(nwv * 64));
+                auto go = [&](auto kern) -> int {
+                    if (lds > 64 * 1024) {                              // (more than 64 KiB of dynamic LDS must be asked for, once per kernel and device)
+                        static std::mutex mu;
+                        static std::vector<std::pair<const void*, int>> done;
+                        int dev = 0;
+                        OMNI_HIP(hipGetDevice(&dev));
+                        std::lock_guard<std::mutex> lk(mu);
+                        const std::pair<const void*, int> key(reinterpret_cast<const void*>(kern), dev);
+                        if (std::find(done.begin(), done.end(), key) == done.end()) {
+                            OMNI_HIP(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            done.push_back(key);
+                        }
+                    }
+                    hipLaunchKernelGGL(kern, grid, block, lds, stream, a, (const uint2*)bt.ent, bt.tx, bt.tx * bt.ty, (unsigned)tensor_bytes, slot_bytes, ppb);
+                    OMNI_HIP(hipGetLastError());
+                    return OMNI_OK;
+                };
+#define E2R(P, S_) go(e2p_ref_kernel<T, P, S_>)
+                if (ppw == 1) return sst == 1 ? E2R(1, 1) : sst == 2 ? E2R(1, 2) : E2R(1, 3);
+                return sst == 1 ? E2R(2, 1) : sst == 2 ? E2R(2, 2) : E2R(2, 3);
+#undef E2R
+            }
+        }
         const int tiles_w = (g->pw + E2P_TW - 1) / E2P_TW;
         const size_t lds = sizeof(float) * E2P_CCH * E2P_TW * N;
         if (pair) hipLaunchKernelGGL((e2p_reflayout_kernel<T, true>), dim3(g->ph * tiles_w), dim3(256), lds, stream, a, tiles_w);

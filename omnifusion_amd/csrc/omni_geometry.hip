@@ -43,6 +43,7 @@ const OptName kOpts[] = {
     {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},
     {"e2p_slot_kb", "OMNI_E2P_SLOT_KB", &OmniOptions::e2p_slot_kb, 6},
     {"e2p_tile_h", "OMNI_E2P_TILE_H", &OmniOptions::e2p_tile_h, 0},
+    {"e2p_ref_lds", "OMNI_E2P_REF_LDS", &OmniOptions::e2p_ref_lds, 1},
     {"e2p_store", "OMNI_E2P_STORE", &OmniOptions::e2p_store, 1},
     {"e2p_slots", "OMNI_E2P_SLOTS", &OmniOptions::e2p_slots, 0},
     {"e2p_split", "OMNI_E2P_SPLIT", &OmniOptions::e2p_split, 0},

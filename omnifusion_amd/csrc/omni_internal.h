@@ -50,6 +50,7 @@ struct OmniOptions {
     int e2p_fb_planes;    // OMNI_E2P_FB_PLANES  planes per gather block of a pole tile (0: 12)
     int e2p_region;       // OMNI_E2P_REGION     which tiles share an XCD: 0 ERP sectors (4 longitudes x 2 hemispheres) | 1 eight latitude bands of equal cost
     int e2p_fb_pos;       // OMNI_E2P_FB_POS     where the gather blocks go: 0 / 3 first | 1 behind the whole tiles | 2 behind the first plane range of the cut tiles | 4 last
+    int e2p_ref_lds;      // OMNI_E2P_REF_LDS    1 (default): the reference layout [B,C,ph,pw,N] by the LDS-staged kernel (e2p_ref_kernel) where a block fits the CU | 0: gathers (e2p_reflayout_kernel)
     int e2p_tile_h;       // OMNI_E2P_TILE_H     sample rows per tile of the equi2pers box kernel: 0 / 8 (default) | 4 | 2: 4 where > 1/8 of the 8-row tiles would gather (measured: wins only at 8 panoramas of 128^2 patches)
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
     int p2e_band;         // OMNI_P2E_BAND       tile rows per XCD band of the pers2equi block order (0: max(1, tile rows / 8) — ONE contiguous range of tile rows per XCD)

@@ -379,6 +379,30 @@ def test_flat_pipeline_kernel_gives_the_bits_of_the_other_two(cfg):
         assert torch.equal(walk, lds) and torch.equal(walk, gat), f"conf {cfg} {dt}"
 
 
+@pytest.mark.parametrize("cfg", [(8, 3, 512, 1024, 4, 256), (1, 3, 512, 1024, 4, 128), (3, 1, 512, 1024, 3, 128), (2, 2, 256, 512, 4, 64),
+                                 (1, 1, 1024, 2048, 4, 256), (5, 1, 128, 256, 3, 32)])
+def test_reference_layout_equi2pers_lds_kernel_gives_the_bits_of_the_gathers(cfg):
+    """equi2pers into the reference's own layout [B,C,ph,pw,N] (equi2pers_v3.py:112-113; what the drop-in returns): e2p_ref_kernel (round 4: a block
+    per tile position of all N patches, boxes by LDS-DMA, the [row][column][patch] tile through LDS) against e2p_reflayout_kernel (gathers) and against
+    the planar kernel's output re-laid — torch.equal, fp32 and fp16, pole tiles (gather path inside the block) included."""
+    _, equi2pers_patches, _, _, L = _ops()
+    B, C, H, W, nrows, P = cfg
+    lib = L.load()
+    for dt in (torch.float32, torch.float16):
+        x = torch.rand((B, C, H, W), device=DEV).to(dt)
+        outs = {}
+        for v in (1, 0):
+            L.set_option("e2p_ref_lds", v); lib.omni_geometry_cache_clear()
+            try:
+                outs[v] = equi2pers_patches(x, 80, nrows, P).clone()
+            finally:
+                L.set_option("e2p_ref_lds", 1)
+        assert torch.equal(outs[0], outs[1]), f"{cfg} {dt}: {(outs[0].float() - outs[1].float()).abs().max().item()}"
+        planar = equi2pers_patches(x, 80, nrows, P, layout=L.LAYOUT_BNCHW)
+        assert torch.equal(planar.permute(0, 2, 3, 4, 1).contiguous(), outs[1])
+    lib.omni_geometry_cache_clear()
+
+
 @pytest.mark.parametrize("cfg", [(8, 1, 512, 1024, 4, 256, "float32"), (2, 3, 256, 512, 6, 64, "float32"), (1, 2, 128, 256, 3, 20, "float16"),
                                  (3, 1, 64, 128, 5, 17, "float32")])
 def test_reference_layout_blend_via_planar_gives_the_same_bits(cfg):

@@ -142,16 +142,17 @@ def kernel_us_rotating(make_fn, inputs, dev, reps=20):
     return float(np.mean(ts))
 
 
-def resample_pair(dev, B, H, W, nrows, P, dtype, reps=20):
-    """The resample pair (equi2pers C = 3, pers2equi C = 1, planar layout) at one BASELINE shape: seconds per kernel + algorithmic bytes."""
+def resample_pair(dev, B, H, W, nrows, P, dtype, reps=20, ref_layout=False):
+    """The resample pair (equi2pers C = 3, pers2equi C = 1) at one BASELINE shape: seconds per kernel + algorithmic bytes.  Planar layout (what the
+    model uses inside) or, ref_layout=True, the reference's own [B,C,ph,pw,N] (what the drop-in equi2pers() returns / pers2equi() takes)."""
     from omnifusion_amd import _lib
     from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
     from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi
     N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
     s = 2 if dtype == torch.float16 else 4
     x = torch.rand((B, 3, H, W), device=dev).to(dtype)
-    d = torch.rand((B, N, 1, P, P), device=dev).to(dtype)
-    LAY = _lib.LAYOUT_BNCHW
+    d = (torch.rand((B, 1, P, P, N), device=dev) if ref_layout else torch.rand((B, N, 1, P, P), device=dev)).to(dtype)
+    LAY = _lib.LAYOUT_BCHWN if ref_layout else _lib.LAYOUT_BNCHW
     t1, t2 = kernel_us([lambda: equi2pers_patches(x, FOV, nrows, (P, P), layout=LAY),
                         lambda: pers2equi(d, FOV, nrows, (P, P), (H, W), None, layout=LAY)], dev, reps)
     b1, b2 = B * 3 * (H * W + P * P * N) * s, B * (P * P * N + H * W) * s
@@ -250,6 +251,8 @@ def main():
     configs = {}
     if rank == 0:
         configs["b16"] = resample_pair(dev, 16, ERP_H, ERP_W, NROWS, 256, torch.float32)
+        configs["reference_layout"] = resample_pair(dev, B, ERP_H, ERP_W, NROWS, 256, torch.float32, ref_layout=True)
+        configs["reference_layout"]["note"] = "the same pair through the reference's own patch layout [B,C,256,256,18] (N innermost, equi2pers_v3.py:112-113): what the drop-in functions return / take; pers2equi = conversion to planar + the planar kernel"
         configs["cfg3"] = resample_pair(dev, 1, 1024, 2048, 6, 256, torch.float32)
         configs["cfg5"] = {"fp16": resample_pair(dev, 1, 2048, 4096, 6, 512, torch.float16),
                            "fp32": resample_pair(dev, 1, 2048, 4096, 6, 512, torch.float32),

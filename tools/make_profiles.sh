@@ -28,4 +28,9 @@ cd $R
   python tools/kbench.py --B 4 --P 512 --H 2048 --W 4096 --nrows 6 --half; } 2>&1 | grep -v amdgpu.ids > $O/${tag}_resample_shapes.txt
 tools/pmc_resample.sh ${tag}r --iters 5 > $O/${tag}_resample_pmc.txt 2>&1
 tools/pmc_traffic.sh $tag 8 > /dev/null 2>&1
+tools/pmc_net.sh $tag 8 > /dev/null 2>&1
+tools/pmc_conv.sh $tag > /dev/null 2>&1
+tools/pmc_single.sh $tag > /dev/null 2>&1
+{ echo "# equi2pers / pers2equi in the reference layout [B,C,ph,pw,N] (what the drop-in functions return / take): tools/kbench.py --layout ref; ref_lds=0: the gather kernel";
+  for v in 1 0; do for a in "--B 8" "--B 8 --P 128" "--B 1" "--B 16"; do OMNI_E2P_REF_LDS=$v python tools/kbench.py --layout ref $a 2>&1 | grep -v amdgpu.ids | sed "s/^/ref_lds=$v /"; done; done; } > $O/${tag}_ref_layout.txt
 ls -la $O | grep $tag

@@ -9,7 +9,7 @@ idx = [i for i, r in enumerate(rows) if "e2p_box_kernel" in r["Kernel_Name"] or 
 start = None
 for i in reversed(idx):
     start = i
-    nxt = [j for j in range(i + 1, len(rows)) if "p2e_lds_kernel" in rows[j]["Kernel_Name"] or "p2e_kernel" in rows[j]["Kernel_Name"]]
+    nxt = [j for j in range(i + 1, len(rows)) if any(t in rows[j]["Kernel_Name"] for t in ("p2e_lds_kernel", "p2e_walk_kernel", "p2e_kernel"))]
     if nxt and nxt[0] - i > 50:
         end = nxt[0]
         break

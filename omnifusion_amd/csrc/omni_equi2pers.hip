@@ -1137,41 +1137,41 @@ __global__ __launch_bounds__(PPW == 1 ? 1024 : 640) void e2p_ref_kernel(E2PArgs 
         auto plane = [&]<int NBC>(std::integral_constant<int, NBC>, int p) {
             T* ot = otile + (size_t)(p & 1) * out_elems;
             const bool refill = p + nb < np;
+            // ONE wait for all my boxes of this plane: behind the last of them the queue holds the boxes of the NBC - 1 planes ahead and the stores
+            // of the NBC planes before this one (a plane's boxes are refilled together, after all of them have been read)
+            if constexpr (SYNC || NBC == 0) e2b_wait_vm<0>();
+            else e2b_wait_vm<(NBC - 1) * PPW * NJ + NBC * S>();
+            float v[PPW][NPX][4];
             for_j([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if (!valid[j]) return;                              // (wave-uniform)
-                float r[NPX];
                 if (fits[j]) {
-                    // steady state: behind box (j, p) the queue holds the other NBC PPW - 1 boxes in flight and the stores of the NBC planes before this one
-                    if constexpr (SYNC || NBC == 0) e2b_wait_vm<0>();
-                    else e2b_wait_vm<(NBC * PPW - 1) * NJ + NBC * S>();
                     const unsigned char* box = ring + (unsigned)j * (unsigned)slot_bytes + (unsigned)((p & (nb - 1)) * NJ * 1024);
 #pragma unroll
                     for (int k = 0; k < NPX; ++k) {
-                        float a0, a1, b0, b1;
-                        E2BPair<T>::ld(box, r0[j][k], a0, a1);
-                        E2BPair<T>::ld(box, r1[j][k], b0, b1);
-                        r[k] = e2p_blend(a0, a1, b0, b1, w00[j][k], w01[j][k], w10[j][k], w11[j][k]);
+                        E2BPair<T>::ld(box, r0[j][k], v[j][k][0], v[j][k][1]);
+                        E2BPair<T>::ld(box, r1[j][k], v[j][k][2], v[j][k][3]);
                     }
-                    if (refill) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(jc, p + nb); }
-                } else {
-                    // (a pole tile: direct gathers of this plane's taps)
-                    if constexpr (SYNC) {
-                        const T* im = (const T*)a.erp + (size_t)(p_begin + p) * img_plane;
+                } else if constexpr (SYNC) {                        // (a pole tile: direct gathers of this plane's taps)
+                    const T* im = (const T*)a.erp + (size_t)(p_begin + p) * img_plane;
 #pragma unroll
-                        for (int k = 0; k < NPX; ++k) {
-                            float a0, a1, b0, b1;
-                            Pair<T>::ld(im + g0[j][k], a0, a1);
-                            Pair<T>::ld(im + g1[j][k], b0, b1);
-                            r[k] = e2p_blend(a0, a1, b0, b1, w00[j][k], w01[j][k], w10[j][k], w11[j][k]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NPX; ++k) r[k] = 0.0f;  // (not reached: a wave without a gather patch)
+                    for (int k = 0; k < NPX; ++k) {
+                        Pair<T>::ld(im + g0[j][k], v[j][k][0], v[j][k][1]);
+                        Pair<T>::ld(im + g1[j][k], v[j][k][2], v[j][k][3]);
                     }
                 }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every box of this plane has been read: its slots are DMA targets again
+            if (refill) for_j([&](auto jc) { constexpr int j = decltype(jc)::value; if (valid[j] && fits[j]) issue(jc, p + nb); });
+            for_j([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (!valid[j]) return;
 #pragma unroll
-                for (int k = 0; k < NPX; ++k) Store<T>::st(ot + oi[j] + k * OSTEP, r[k]);
+                for (int k = 0; k < NPX; ++k) {
+                    float r = 0.0f;
+                    if (SYNC || fits[j]) r = e2p_blend(v[j][k][0], v[j][k][1], v[j][k][2], v[j][k][3], w00[j][k], w01[j][k], w10[j][k], w11[j][k]);
+                    Store<T>::st(ot + oi[j] + k * OSTEP, r);
+                }
             });
             __syncthreads();                                        // the tile of plane p is complete (and the tile of plane p-1 has been read by everybody)
             // the tile leaves as 16-byte pieces; EVERY wave issues exactly S store instructions (a thread past the end repeats the last piece)

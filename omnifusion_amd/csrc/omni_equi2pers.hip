@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <utility>
 #include "omni_internal.h"
+#include "omni_spgather.h"
 
 namespace {
 
@@ -1703,6 +1704,27 @@ __global__ __launch_bounds__(256) void e2p_bwd_box_kernel(E2PArgs a, int* __rest
     }
 }
 
+// The transpose as a sparse matrix (omni_spgather.h): every tap of every patch sample is one entry (source = the sample, packed
+// patch << 24 | h * pw + w; weight = the bilinear weight) of the row of the ERP pixel it reads.  Taps as in e2p_bwd_kernel.
+__global__ __launch_bounds__(256) void e2p_sp_walk_kernel(E2PArgs a, int total, SpEmit b)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= total) return;
+    const int pp = a.ph * a.pw, n = s / pp;
+    const unsigned src = ((unsigned)n << 24) | (unsigned)(s - n * pp);
+    const float2 c = a.ixy[s];
+    if (!(c.x == c.x) || !(c.y == c.y)) return;                   // q4: an odd x odd patch has a NaN centre sample
+    const float fx = floorf(c.x), fy = floorf(c.y);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = c.x - fx, ty = c.y - fy, ex = 1.0f - tx, ey = 1.0f - ty;
+    const bool okx = x0 + 1 < a.W, oky = y0 + 1 < a.H;
+    const int row = y0 * a.W + x0;
+    sp_emit(b, row, src, ey * ex);
+    if (okx) sp_emit(b, row + 1, src, ey * tx);
+    if (oky) sp_emit(b, row + a.W, src, ty * ex);
+    if (okx && oky) sp_emit(b, row + a.W + 1, src, ty * tx);
+}
+
 template <int PL, int NT>
 __global__ __launch_bounds__(NT) void e2p_bwd_gather_kernel(E2PArgs a /* erp = g_erp (out), pers = g_pers (in) */, const int4* __restrict__ boxes,
                                                             const int* __restrict__ ids, int gtx, int planes, int n_fastest)
@@ -1804,6 +1826,28 @@ int omni_e2p_build_bwd(omni_geometry* g, hipStream_t stream)
     OMNI_HIP(hipMalloc((void**)&g->e2p_bwd_ids, sizeof(int) * ntiles));
     OMNI_HIP(hipMemcpy(g->e2p_bwd_ids, small.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice));
     g->e2p_bwd_ok = 1;
+    // the sparse-matrix form (the default): rows = ERP pixels, sources = patch samples (patch in the high 8 bits, sample in the low 24)
+    if ((long long)g->H * g->W < (1ll << 31) && (long long)g->ph * g->pw <= (1ll << 24) && g->N < 256) {
+        SpBuilder sb;
+        int rc = sb.begin(&g->e2p_sp, g->H * g->W);
+        if (rc != OMNI_OK) return rc;
+        hipLaunchKernelGGL(e2p_sp_walk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, (int)total, sb.emit(0));
+        OMNI_HIP(hipGetLastError());
+        OMNI_HIP(hipStreamSynchronize(stream));
+        bool fits = false;
+        rc = sb.layout((size_t)omni_options().bwd_table_mb << 20, &fits);
+        if (rc != OMNI_OK) return rc;
+        if (fits) {
+            hipLaunchKernelGGL(e2p_sp_walk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, (int)total, sb.emit(1));
+            OMNI_HIP(hipGetLastError());
+            OMNI_HIP(hipStreamSynchronize(stream));
+            rc = sb.finish(stream);
+            if (rc != OMNI_OK) return rc;
+        } else omni_sp_free(g->e2p_sp);
+        if (omni_options().e2p_verbose)
+            fprintf(stderr, "[omni] equi2pers backward as a sparse matrix: %d rows, %lld entries (%lld with padding) + %d long rows with %lld entries%s\n",
+                    g->e2p_sp.nrows, g->e2p_sp.nent, g->e2p_sp.npadded, g->e2p_sp.nlong, g->e2p_sp.nlong_ent, fits ? "" : " -> over the table budget, not kept");
+    }
     return OMNI_OK;
 }
 
@@ -1829,7 +1873,16 @@ extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dty
         }
     }
     const int mode = omni_options().e2p_bwd_simple;
-    // mode 0 (default): whichever is faster for the layout — measured at B = 8, cfg 1: planar 0.74 ms (LDS boxes + coalesced global atomics) vs
+    if (g->e2p_sp.ok && (mode == 0 || mode == 4)) {               // the sparse-matrix gather: no atomics, nothing to zero
+        SpApply s;
+        const long long pp = (long long)ph * pw;
+        s.src = (const float*)grad_pers; s.dst = (float*)grad_erp; s.C = C; s.planes = B * C;
+        if (layout == OMNI_LAYOUT_BNCHW) { s.s_sB = (long long)g->N * C * pp; s.s_sC = pp; s.s_hi = (int)(C * pp); s.s_lo = 1; }
+        else                             { s.s_sB = (long long)C * pp * g->N; s.s_sC = pp * g->N; s.s_hi = 1; s.s_lo = g->N; }
+        s.d_sB = (long long)C * H * W; s.d_sC = (long long)H * W; s.rdiv = 0x7fffffff; s.d_hi = 0; s.d_lo = 1;
+        if ((long long)g->N * C * pp < (1ll << 31)) return sp_apply(g->e2p_sp, s, (hipStream_t)stream);
+    }
+    // without the table, mode 0: whichever is faster for the layout — measured at B = 8, cfg 1: planar 0.74 ms (LDS boxes + coalesced global atomics) vs
     // 0.88 ms (gathers); reference layout 0.88 ms (gathers) vs 3.17 ms (plain scatter).  3 forces the gathers, 1 the plain scatter, 2 the LDS boxes.
     const bool planar_boxes = layout == OMNI_LAYOUT_BNCHW && g->W >= 2;
     if (g->e2p_bwd_ok && (mode == 3 || (mode == 0 && !planar_boxes))) {

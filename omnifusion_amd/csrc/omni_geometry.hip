@@ -39,6 +39,7 @@ const OptName kOpts[] = {
     {"e2p_verbose", "OMNI_E2P_VERBOSE", &OmniOptions::e2p_verbose, 0},
     {"e2p_bwd_simple", "OMNI_E2P_BWD_SIMPLE", &OmniOptions::e2p_bwd_simple, 0},
     {"p2e_bwd_simple", "OMNI_P2E_BWD_SIMPLE", &OmniOptions::p2e_bwd_simple, 0},
+    {"bwd_table_mb", "OMNI_BWD_TABLE_MB", &OmniOptions::bwd_table_mb, 1024},
     {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
     {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},
     {"e2p_slot_kb", "OMNI_E2P_SLOT_KB", &OmniOptions::e2p_slot_kb, 6},
@@ -232,6 +233,17 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
     return OMNI_OK;
 }
 
+void omni_sp_free(OmniSpTable& t)
+{
+    if (t.ent) (void)hipFree(t.ent);
+    if (t.slice_off) (void)hipFree(t.slice_off);
+    if (t.cnt) (void)hipFree(t.cnt);
+    if (t.long_ent) (void)hipFree(t.long_ent);
+    if (t.long_off) (void)hipFree(t.long_off);
+    if (t.long_row) (void)hipFree(t.long_row);
+    t = OmniSpTable();
+}
+
 extern "C" void omni_geometry_destroy(omni_geometry_t* g)
 {
     if (!g) return;
@@ -247,6 +259,7 @@ extern "C" void omni_geometry_destroy(omni_geometry_t* g)
     if (g->e2p_ixy) (void)hipFree(g->e2p_ixy);
     if (g->e2p_bwd_box) (void)hipFree(g->e2p_bwd_box);
     if (g->e2p_bwd_ids) (void)hipFree(g->e2p_bwd_ids);
+    omni_sp_free(g->p2e_sp); omni_sp_free(g->e2p_sp);
     delete g;
 }
 

@@ -39,8 +39,8 @@ struct OmniOptions {
     int e2p_gather;       // OMNI_E2P_GATHER     1: equi2pers always takes the direct-gather kernel (no LDS staging)
     int e2p_notab;        // OMNI_E2P_NOTAB      1: no per-geometry sampling-coordinate table
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built
-    int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 0: fastest per layout (planar: LDS boxes + global atomics; reference layout: ERP-tile gathers, no global atomics) | 1: plain scatter | 2: LDS boxes | 3: gathers
-    int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 1: pers2equi backward by global atomics (the round-1 kernel) instead of patch-tile gathers
+    int e2p_bwd_simple;   // OMNI_E2P_BWD_SIMPLE 0 (default) | 4: the sparse-matrix gather (omni_spgather.h; no atomics, fixed summation order) | 1: plain scatter | 2: LDS boxes + global atomics | 3: ERP-tile gathers with LDS atomics
+    int p2e_bwd_simple;   // OMNI_P2E_BWD_SIMPLE 0 (default): the sparse-matrix gather | 1: global atomics (the round-1 kernel) | 2: patch-tile gathers with LDS atomics
     int p2e_gather;       // OMNI_P2E_GATHER     1: pers2equi always takes the direct-gather kernel (no LDS staging) | 2: never (not even for ONE plane of a large ERP)
     int e2p_nbuf;         // OMNI_E2P_NBUF       LDS ring slots (boxes in flight) per wave of the equi2pers LDS kernel: 0 auto | 1 | 2 | 4
     int e2p_store;        // OMNI_E2P_STORE      patch stores of the equi2pers box kernel: 0 plain | 1 non-temporal (default: 106 -> 64-74 us at 16 panoramas, whose 327 MB per launch exceed the 256-MB memory-side cache)
@@ -58,6 +58,7 @@ struct OmniOptions {
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
     int p2e_store;        // OMNI_P2E_STORE      ERP stores of the pers2equi LDS kernels: 1 (default) non-temporal | 0 plain
     int p2e_walk;         // OMNI_P2E_WALK       1 (default): the flat-pipeline kernel p2e_walk_kernel (one stage stream per tile across its patches, stages consumed in pairs) | 0: p2e_lds_kernel (patch by patch)
+    int bwd_table_mb;     // OMNI_BWD_TABLE_MB   largest sparse-matrix table of a backward operator kept per geometry, MiB (default 1024; a geometry past it keeps the tile kernels)
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
 OmniOptions& omni_options();
@@ -85,6 +86,19 @@ struct PatchTab {
     float sphi[OMNI_MAX_PATCH];    // sin / cos of the fp32 centre latitude (:84)
     float cphi[OMNI_MAX_PATCH];
 };
+
+// A linear operator of the geometry as a sparse matrix in sliced-ELL form (omni_spgather.h): rows in slices of 64 (one per lane of a wave), slice s
+// holds K_s = slice_off[s+1] - slice_off[s] entries per row, entry k of row r at ent[(slice_off[s] * 64) + k * 64 + (r & 63)]; cnt[r] of them are
+// real.  Rows with more than OMNI_SP_LMAX entries (patch pixels at a pole: a whole ERP row maps onto them) live in a CSR side list instead
+// (cnt[r] = -1) and get a block each.  Entries of a row are sorted by source index: the summation order is a constant of the geometry.
+constexpr int OMNI_SP_LMAX = 24;
+struct OmniSpTable {
+    uint2* ent = nullptr; int* slice_off = nullptr; int* cnt = nullptr;
+    uint2* long_ent = nullptr; int* long_off = nullptr; int* long_row = nullptr;
+    int nrows = 0, nslices = 0, nlong = 0, ok = 0;
+    long long nent = 0, npadded = 0, nlong_ent = 0;
+};
+void omni_sp_free(OmniSpTable& t);
 
 struct omni_geometry {
     int device;
@@ -122,6 +136,8 @@ struct omni_geometry {
     float2* e2p_ixy;               // equi2pers: clamped sampling coordinates (ix, iy) of every patch sample [N][ph][pw]
     // equi2pers backward by gathers (omni_equi2pers.hip): per (4 x 32 ERP tile, patch) the box of the patch samples whose taps touch the tile
     int4* e2p_bwd_box; int* e2p_bwd_ids; int e2p_bwd_nsmall, e2p_bwd_nbig, e2p_gtx, e2p_gty, e2p_bwd_ok;
+    // the backward operators as constant sparse matrices (omni_spgather.h): one row per OUTPUT element, entries (source index, weight)
+    OmniSpTable p2e_sp, e2p_sp;
     // the two backward tables are built by the FIRST backward call of the geometry (3.7 ms of one-time kernels a forward-only user never pays)
     std::mutex bwd_mu; int p2e_bwd_tried = 0, e2p_bwd_tried = 0;
 };

@@ -29,6 +29,7 @@
 #include <vector>
 #include <algorithm>
 #include "omni_internal.h"
+#include "omni_spgather.h"
 
 namespace {
 
@@ -1311,6 +1312,32 @@ __global__ __launch_bounds__(256) void p2e_bwd_box_kernel(P2EArgs a, int* __rest
     if (inside) rden[(size_t)i * a.W + j] = 1.0f / fmaxf(l1, 1e-12f);
 }
 
+// The transpose as a sparse matrix (omni_spgather.h): every (ERP pixel, covering patch, tap with a non-zero weight) is one entry
+// (source = the pixel, weight = w_tap / l1) of the row of the patch pixel the tap reads.  Same traversal and tap function as above.
+__global__ __launch_bounds__(256) void p2e_sp_walk_kernel(P2EArgs a, const float* __restrict__ rden, SpEmit b)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = blockIdx.x % a.ntx;
+    const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.ntx) * 4 + wave);
+    const int j = tx * 64 + lane;
+    if (i >= a.H || j >= a.W) return;
+    const float2 rt = a.row_trig[i], ct = a.col_trig[j];
+    const size_t pix = (size_t)i * a.W + j;
+    const float r = rden[pix];
+    const unsigned long long cm_ = a.cand[(size_t)i * a.ntx + tx];
+    const unsigned cm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ >> 32));
+    const unsigned cm_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(cm_ & 0xffffffffull));
+    for (unsigned long long m = ((unsigned long long)cm_hi << 32) | (unsigned long long)cm_lo; m;) {
+        const int n = __builtin_ctzll(m); m &= m - 1;
+        Taps t; p2e_taps(a, n, rt.x, rt.y, ct.x, ct.y, t);
+        const int xs[2] = {t.x0, t.x1}, ys[2] = {t.y0, t.y1};
+        const float w[4] = {t.wa, t.wb, t.wc, t.wd};               // (y0,x0) (y1,x0) (y0,x1) (y1,x1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (w[k] != 0.0f) sp_emit(b, (n * a.ph + ys[k & 1]) * a.pw + xs[k >> 1], (unsigned)pix, w[k] * r);
+    }
+}
+
 // NT threads per tile: 64 for the ordinary tiles, 1024 for the few polar ones whose box is whole ERP rows (tens of thousands of pixels)
 template <int PL, int NT>
 __global__ __launch_bounds__(NT) void p2e_bwd_gather_kernel(P2EArgs a /* erp = g_erp (in), pers = g_pers (out) */, const int4* __restrict__ boxes,
@@ -1414,6 +1441,29 @@ int omni_p2e_build_bwd(omni_geometry* g, hipStream_t stream)
     OMNI_HIP(hipMalloc((void**)&g->p2e_bwd_ids, sizeof(int) * ntiles));
     OMNI_HIP(hipMemcpy(g->p2e_bwd_ids, small.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice));
     g->p2e_bwd_ok = 1;
+    // the sparse-matrix form (the default): rows = patch pixels.  (ERP pixel indices must fit the 24-bit source field.)
+    const long long nrows = (long long)g->N * g->ph * g->pw;
+    if (nrows < (1ll << 31) && (long long)g->H * g->W <= (1ll << 24)) {
+        SpBuilder sb;
+        rc = sb.begin(&g->p2e_sp, (int)nrows);
+        if (rc != OMNI_OK) return rc;
+        hipLaunchKernelGGL(p2e_sp_walk_kernel, dim3(rows4 * g->ntx), dim3(256), 0, stream, a, (const float*)g->p2e_rden, sb.emit(0));
+        OMNI_HIP(hipGetLastError());
+        OMNI_HIP(hipStreamSynchronize(stream));
+        bool fits = false;
+        rc = sb.layout((size_t)omni_options().bwd_table_mb << 20, &fits);
+        if (rc != OMNI_OK) return rc;
+        if (fits) {
+            hipLaunchKernelGGL(p2e_sp_walk_kernel, dim3(rows4 * g->ntx), dim3(256), 0, stream, a, (const float*)g->p2e_rden, sb.emit(1));
+            OMNI_HIP(hipGetLastError());
+            OMNI_HIP(hipStreamSynchronize(stream));
+            rc = sb.finish(stream);
+            if (rc != OMNI_OK) return rc;
+        } else omni_sp_free(g->p2e_sp);
+        if (omni_options().e2p_verbose)
+            fprintf(stderr, "[omni] pers2equi backward as a sparse matrix: %d rows, %lld entries (%lld with padding) + %d long rows with %lld entries%s\n",
+                    g->p2e_sp.nrows, g->p2e_sp.nent, g->p2e_sp.npadded, g->p2e_sp.nlong, g->p2e_sp.nlong_ent, fits ? "" : " -> over the table budget, not kept");
+    }
     return OMNI_OK;
 }
 
@@ -1440,7 +1490,14 @@ extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dty
             if (rc != OMNI_OK) return rc;
         }
     }
-    if (g->p2e_bwd_ok && !omni_options().p2e_bwd_simple) {
+    if (g->p2e_sp.ok && omni_options().p2e_bwd_simple == 0 && a.sY == (long long)pw * a.sX) {
+        SpApply s;
+        s.src = (const float*)grad_erp; s.dst = (float*)grad_pers; s.C = C; s.planes = B * C;
+        s.s_sB = (long long)C * H * W; s.s_sC = (long long)H * W; s.s_hi = 0; s.s_lo = 1;
+        s.d_sB = a.sB; s.d_sC = a.sC; s.rdiv = ph * pw; s.d_hi = a.sN; s.d_lo = (int)a.sX;
+        return sp_apply(g->p2e_sp, s, (hipStream_t)stream);
+    }
+    if (g->p2e_bwd_ok && omni_options().p2e_bwd_simple != 1) {
         constexpr int PL = 4;
         const int groups = (B * C + PL - 1) / PL;
         if (g->p2e_bwd_nbig)                                      // first: they are the long ones

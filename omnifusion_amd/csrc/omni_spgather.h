@@ -1,0 +1,235 @@
+// omni_spgather.h — the backward of equi2pers / pers2equi as a CONSTANT SPARSE MATRIX applied by gathers (gfx950).
+//
+// Both operators are linear maps whose coefficients depend on the geometry only (bilinear tap weights; for pers2equi also the L1
+// normaliser of the ERP pixel), so their transposes are sparse matrices that can be written down once per geometry handle:
+//   pers2equi^T:  g_pers[n, y, x]  = sum over the ERP pixels whose taps in patch n touch (y, x) of (w_tap / l1) * g_erp[pixel]
+//                 (what autograd derives from the advanced-indexing gathers of pers2equi_v3.py:174-196)
+//   equi2pers^T:  g_erp[i, j]      = sum over the patch samples whose taps touch (i, j) of w_tap * g_pers[n, h, w]
+//                 (ATen grid_sampler_2d_backward, bilinear / border / align_corners=True, equi2pers_v3.py:111)
+// ~4 and ~9 entries per output element.  The kernels of rounds 2-3 re-derived the taps on every call and reduced them through LDS or global
+// atomics (0.32 / 0.74 ms at B = 8, 512 x 1024, 18 x 256^2: 0.17 / 0.22 TB/s); here a call is one pass over the 8-byte entries (coalesced: the
+// sliced-ELL layout puts entry k of 64 consecutive rows side by side), one gather per entry and plane from a source that sits in L2, one
+// coalesced store per output element — no atomics anywhere, and the summation order is a constant of the geometry (entries sorted by source).
+//
+// Included by omni_pers2equi.hip and omni_equi2pers.hip (each walks its own taps to emit the entries; everything else is shared).
+#pragma once
+#include <algorithm>
+#include <vector>
+#include "omni_internal.h"
+
+namespace {
+
+// how one application addresses its operands: source element of entry e (hi 8 bits | lo 24 bits of e.x) and plane p, destination of row r
+struct SpApply {
+    const uint2* ent; const int* slice_off; const int* cnt; int nrows, nslices;
+    const uint2* long_ent; const int* long_off; const int* long_row;
+    const float* src; float* dst;
+    int C, planes;                        // plane p = (batch p / C, channel p % C)
+    long long s_sB, s_sC, d_sB, d_sC;     // element strides of batch / channel in source and destination
+    int s_hi, s_lo;                       // source offset inside a plane: (e.x >> 24) * s_hi + (e.x & 0xffffff) * s_lo
+    int rdiv; long long d_hi; int d_lo;   // destination offset of row r inside a plane: (r / rdiv) * d_hi + (r % rdiv) * d_lo
+};
+
+// One wave per slice of 64 rows, PL planes in registers.
+template <int PL>
+__global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s)
+{
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (slice >= s.nslices) return;
+    const int row = slice * 64 + lane, p0 = blockIdx.y * PL;
+    const int o0 = s.slice_off[slice], K = s.slice_off[slice + 1] - o0;
+    const int nk = row < s.nrows ? s.cnt[row] : -1;
+    const float* sp[PL];
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+        const int pl = min(p0 + p, s.planes - 1);
+        sp[p] = s.src + (size_t)(pl / s.C) * s.s_sB + (size_t)(pl % s.C) * s.s_sC;
+    }
+    float acc[PL];
+#pragma unroll
+    for (int p = 0; p < PL; ++p) acc[p] = 0.0f;
+    const uint2* e = s.ent + (size_t)o0 * 64 + lane;
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+        const uint2 en = e[(size_t)k * 64];
+        if (k < nk) {
+            const int off = (int)(en.x >> 24) * s.s_hi + (int)(en.x & 0xffffffu) * s.s_lo;
+            const float w = __uint_as_float(en.y);
+#pragma unroll
+            for (int p = 0; p < PL; ++p) acc[p] = fmaf(sp[p][off], w, acc[p]);
+        }
+    }
+    if (nk < 0) return;                                           // past the end, or a long row (sp_long_kernel writes it)
+    const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
+#pragma unroll
+    for (int p = 0; p < PL; ++p)
+        if (p0 + p < s.planes) s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = acc[p];
+}
+
+// One block of 256 threads per long row (fixed partition of the entries and fixed reduction tree: deterministic).
+template <int PL>
+__global__ __launch_bounds__(256) void sp_long_kernel(SpApply s)
+{
+    __shared__ float part[4][PL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = s.long_row[blockIdx.x], o0 = s.long_off[blockIdx.x], o1 = s.long_off[blockIdx.x + 1], p0 = blockIdx.y * PL;
+    const float* sp[PL];
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+        const int pl = min(p0 + p, s.planes - 1);
+        sp[p] = s.src + (size_t)(pl / s.C) * s.s_sB + (size_t)(pl % s.C) * s.s_sC;
+    }
+    float acc[PL];
+#pragma unroll
+    for (int p = 0; p < PL; ++p) acc[p] = 0.0f;
+    for (int i = o0 + (int)threadIdx.x; i < o1; i += 256) {
+        const uint2 en = s.long_ent[i];
+        const int off = (int)(en.x >> 24) * s.s_hi + (int)(en.x & 0xffffffu) * s.s_lo;
+        const float w = __uint_as_float(en.y);
+#pragma unroll
+        for (int p = 0; p < PL; ++p) acc[p] = fmaf(sp[p][off], w, acc[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+        float v = acc[p];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) part[wave][p] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PL && p0 + (int)threadIdx.x < s.planes) {
+        const int p = threadIdx.x;
+        const float v = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
+        const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
+        s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
+    }
+}
+
+// ---- building a table.  The operator's own file walks its taps twice with sp_emit: pass 0 counts the entries of every row, pass 1 deposits
+// them (slot = the row's running cursor); sp_sort_kernel then orders every row by source index so that the result does not depend on the
+// order the atomics of pass 1 happened to take.
+struct SpEmit {
+    int pass;                 // 0: count, 1: fill
+    int* cnt;                 // pass 0: entries per row; pass 1: the cursor (zeroed again)
+    const int* rowpos;        // pass 1: >= 0: index of the row's entry 0 in `ent` (stride 64); < 0: -(1 + index in long_ent) (stride 1)
+    uint2* ent; uint2* long_ent;
+};
+__device__ __forceinline__ void sp_emit(const SpEmit& b, int row, unsigned src, float w)
+{
+    if (b.pass == 0) { atomicAdd(b.cnt + row, 1); return; }
+    const int slot = atomicAdd(b.cnt + row, 1), rp = b.rowpos[row];
+    const uint2 e = make_uint2(src, __float_as_uint(w));
+    if (rp >= 0) b.ent[(size_t)rp + (size_t)slot * 64] = e;
+    else         b.long_ent[(size_t)(-1 - rp) + slot] = e;
+}
+__device__ __forceinline__ bool sp_after(uint2 a, uint2 b) { return a.x > b.x || (a.x == b.x && a.y > b.y); }
+
+__global__ __launch_bounds__(256) void sp_sort_kernel(uint2* ent, const int* __restrict__ slice_off, const int* __restrict__ cnt, int nrows)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    const int n = cnt[row];
+    uint2* e = ent + (size_t)slice_off[row >> 6] * 64 + (row & 63);
+    for (int i = 1; i < n; ++i) {                                  // insertion sort, n <= OMNI_SP_LMAX
+        const uint2 key = e[(size_t)i * 64];
+        int j = i - 1;
+        while (j >= 0 && sp_after(e[(size_t)j * 64], key)) { e[(size_t)(j + 1) * 64] = e[(size_t)j * 64]; --j; }
+        e[(size_t)(j + 1) * 64] = key;
+    }
+}
+
+// Host side of the build.  layout(): from the device counts of pass 0 to the allocated (zeroed) table and the rowpos array of pass 1;
+// finish(): sorts.  `budget` caps the table size in bytes (a geometry past it keeps the older kernels).
+struct SpBuilder {
+    OmniSpTable* t; int* d_cnt = nullptr; int* d_rowpos = nullptr; std::vector<int> h_cnt;
+    ~SpBuilder() { if (d_cnt) (void)hipFree(d_cnt); if (d_rowpos) (void)hipFree(d_rowpos); }
+    int begin(OmniSpTable* table, int nrows)
+    {
+        t = table; t->nrows = nrows; t->nslices = (nrows + 63) / 64;
+        OMNI_HIP(hipMalloc((void**)&d_cnt, sizeof(int) * (size_t)nrows));
+        OMNI_HIP(hipMemset(d_cnt, 0, sizeof(int) * (size_t)nrows));
+        return OMNI_OK;
+    }
+    SpEmit emit(int pass) const { SpEmit e; e.pass = pass; e.cnt = d_cnt; e.rowpos = d_rowpos; e.ent = t->ent; e.long_ent = t->long_ent; return e; }
+    // after pass 0 (stream synchronised by the caller): returns OMNI_OK with t->ok == 0 when the table would exceed `budget`
+    int layout(size_t budget, bool* fits)
+    {
+        const int nrows = t->nrows, ns = t->nslices;
+        h_cnt.resize(nrows);
+        OMNI_HIP(hipMemcpy(h_cnt.data(), d_cnt, sizeof(int) * (size_t)nrows, hipMemcpyDeviceToHost));
+        std::vector<int> so(ns + 1, 0), rowpos(nrows), lrow, loff(1, 0), tcnt(nrows);
+        long long nent = 0, nl = 0;
+        for (int s = 0; s < ns; ++s) {
+            int K = 0;
+            for (int r = s * 64; r < std::min(nrows, s * 64 + 64); ++r) if (h_cnt[r] <= OMNI_SP_LMAX) K = std::max(K, h_cnt[r]);
+            so[s + 1] = so[s] + K;
+            if ((long long)so[s + 1] * 64 >= (1ll << 31)) { *fits = false; return OMNI_OK; }
+        }
+        for (int r = 0; r < nrows; ++r) {
+            if (h_cnt[r] <= OMNI_SP_LMAX) { rowpos[r] = so[r >> 6] * 64 + (r & 63); tcnt[r] = h_cnt[r]; nent += h_cnt[r]; }
+            else {
+                if (nl + h_cnt[r] >= (1ll << 31) - 1) { *fits = false; return OMNI_OK; }
+                rowpos[r] = -1 - (int)nl; tcnt[r] = -1; lrow.push_back(r); nl += h_cnt[r]; loff.push_back((int)nl);
+            }
+        }
+        t->nent = nent; t->npadded = (long long)so[ns] * 64; t->nlong = (int)lrow.size(); t->nlong_ent = nl;
+        const size_t bytes = (size_t)(t->npadded + nl) * sizeof(uint2) + (size_t)nrows * 4;
+        *fits = bytes <= budget;
+        if (!*fits) return OMNI_OK;
+        OMNI_HIP(hipMalloc((void**)&t->ent, sizeof(uint2) * (size_t)std::max<long long>(t->npadded, 1)));
+        OMNI_HIP(hipMemset(t->ent, 0, sizeof(uint2) * (size_t)std::max<long long>(t->npadded, 1)));
+        OMNI_HIP(hipMalloc((void**)&t->long_ent, sizeof(uint2) * (size_t)std::max<long long>(nl, 1)));
+        OMNI_HIP(hipMalloc((void**)&t->slice_off, sizeof(int) * (size_t)(ns + 1)));
+        OMNI_HIP(hipMalloc((void**)&t->cnt, sizeof(int) * (size_t)nrows));
+        OMNI_HIP(hipMalloc((void**)&t->long_off, sizeof(int) * loff.size()));
+        OMNI_HIP(hipMalloc((void**)&t->long_row, sizeof(int) * std::max<size_t>(lrow.size(), 1)));
+        OMNI_HIP(hipMalloc((void**)&d_rowpos, sizeof(int) * (size_t)nrows));
+        OMNI_HIP(hipMemcpy(t->slice_off, so.data(), sizeof(int) * (size_t)(ns + 1), hipMemcpyHostToDevice));
+        OMNI_HIP(hipMemcpy(t->cnt, tcnt.data(), sizeof(int) * (size_t)nrows, hipMemcpyHostToDevice));
+        OMNI_HIP(hipMemcpy(t->long_off, loff.data(), sizeof(int) * loff.size(), hipMemcpyHostToDevice));
+        if (!lrow.empty()) OMNI_HIP(hipMemcpy(t->long_row, lrow.data(), sizeof(int) * lrow.size(), hipMemcpyHostToDevice));
+        OMNI_HIP(hipMemcpy(d_rowpos, rowpos.data(), sizeof(int) * (size_t)nrows, hipMemcpyHostToDevice));
+        OMNI_HIP(hipMemset(d_cnt, 0, sizeof(int) * (size_t)nrows));                // the cursors of pass 1
+        h_loff.swap(loff);
+        return OMNI_OK;
+    }
+    std::vector<int> h_loff;
+    // after pass 1 (stream synchronised by the caller)
+    int finish(hipStream_t stream)
+    {
+        hipLaunchKernelGGL(sp_sort_kernel, dim3((unsigned)((t->nrows + 255) / 256)), dim3(256), 0, stream, t->ent, (const int*)t->slice_off, (const int*)t->cnt, t->nrows);
+        OMNI_HIP(hipGetLastError());
+        if (t->nlong_ent) {                                        // the few long rows: sorted on the host
+            std::vector<uint2> le((size_t)t->nlong_ent);
+            OMNI_HIP(hipMemcpy(le.data(), t->long_ent, sizeof(uint2) * le.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < t->nlong; ++i)
+                std::sort(le.begin() + h_loff[i], le.begin() + h_loff[i + 1], [](const uint2& a, const uint2& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+            OMNI_HIP(hipMemcpy(t->long_ent, le.data(), sizeof(uint2) * le.size(), hipMemcpyHostToDevice));
+        }
+        OMNI_HIP(hipStreamSynchronize(stream));
+        t->ok = 1;
+        return OMNI_OK;
+    }
+};
+
+// launch: planes in groups of 8 (12 where the plane count is a multiple of 12: three-channel images)
+inline int sp_apply(const OmniSpTable& t, SpApply s, hipStream_t stream)
+{
+    s.ent = t.ent; s.slice_off = t.slice_off; s.cnt = t.cnt; s.nrows = t.nrows; s.nslices = t.nslices;
+    s.long_ent = t.long_ent; s.long_off = t.long_off; s.long_row = t.long_row;
+    const unsigned nb = (unsigned)((t.nslices + 3) / 4);
+    if (s.planes > 8 && s.planes % 12 == 0) {
+        const unsigned groups = (unsigned)(s.planes / 12);
+        if (t.nlong) hipLaunchKernelGGL(sp_long_kernel<12>, dim3((unsigned)t.nlong, groups), dim3(256), 0, stream, s);
+        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3(nb, groups), dim3(256), 0, stream, s);
+    } else {
+        const unsigned groups = (unsigned)((s.planes + 7) / 8);
+        if (t.nlong) hipLaunchKernelGGL(sp_long_kernel<8>, dim3((unsigned)t.nlong, groups), dim3(256), 0, stream, s);
+        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3(nb, groups), dim3(256), 0, stream, s);
+    }
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+}  // namespace

@@ -88,7 +88,7 @@ def test_adjoint_identity_config1_size():
 
 
 def test_pers2equi_backward_gather_equals_scatter():
-    """the atomic-free patch-tile gather kernel (default) against the round-1 scatter kernel (global atomics), at the benchmark size,
+    """the sparse-matrix gather (default, mode 0) and the patch-tile gather kernel (mode 2) against the round-1 scatter kernel (global atomics), at the benchmark size,
     at nrows = 6 (boxes that wrap around the +-pi seam and polar tiles that see a whole ERP row) and on ragged patch tiles"""
     _, _, _, L = _ops()
     import ctypes
@@ -100,7 +100,7 @@ def test_pers2equi_backward_gather_equals_scatter():
         ge = torch.rand((B, C, H, W), device=DEV)
         outs = []
         try:
-            for simple in (0, 1):
+            for simple in (0, 1, 2):
                 L.set_option("p2e_bwd_simple", simple)
                 gp = torch.full((B, N, C, ph, pw), float("nan"), device=DEV)
                 rc = lib.omni_pers2equi_bwd(P_(ge), P_(gp), 0, B, C, ph, pw, H, W, nrows, ctypes.c_float(80), ctypes.c_float(80), L.LAYOUT_BNCHW, None)
@@ -109,13 +109,14 @@ def test_pers2equi_backward_gather_equals_scatter():
         finally:
             L.set_option("p2e_bwd_simple", 0)
         torch.cuda.synchronize()
-        assert bool(torch.isfinite(outs[0]).all())
-        d = (outs[0] - outs[1]).abs().max().item()
-        assert d <= 1e-5 * max(1.0, outs[1].abs().max().item()), (nrows, ph, pw, d)
+        assert bool(torch.isfinite(outs[0]).all()) and bool(torch.isfinite(outs[2]).all())
+        for k in (0, 2):
+            d = (outs[k] - outs[1]).abs().max().item()
+            assert d <= 1e-5 * max(1.0, outs[1].abs().max().item()), (nrows, ph, pw, k, d)
 
 
 def test_equi2pers_backward_gather_equals_scatter():
-    """the atomic-free ERP-tile gather kernel (default) against the plain scatter kernel and the round-1 LDS-box kernel (global atomics),
+    """the sparse-matrix gather (default, mode 4), the round-1 LDS-box kernel (global atomics) and the ERP-tile gather kernel against the plain scatter kernel,
     both layouts, the benchmark size, nrows = 6, ragged ERP tiles and odd x odd patches (NaN centre sample, quirk q4)"""
     _, _, _, L = _ops()
     import ctypes
@@ -128,7 +129,7 @@ def test_equi2pers_backward_gather_equals_scatter():
             gp = torch.rand((B, N, C, ph, pw) if layout == L.LAYOUT_BNCHW else (B, C, ph, pw, N), device=DEV)
             outs = []
             try:
-                for mode in (3, 1, 2):
+                for mode in (4, 1, 2, 3):
                     L.set_option("e2p_bwd_simple", mode)
                     ge = torch.full((B, C, H, W), float("nan"), device=DEV)
                     rc = lib.omni_equi2pers_bwd(P_(gp), P_(ge), 0, B, C, H, W, ph, pw, nrows, ctypes.c_float(80), ctypes.c_float(80), layout, None)
@@ -139,6 +140,26 @@ def test_equi2pers_backward_gather_equals_scatter():
             torch.cuda.synchronize()
             assert bool(torch.isfinite(outs[0]).all())
             scale = max(1.0, outs[1].abs().max().item())
-            for k in (1, 2):
-                d = (outs[0] - outs[k]).abs().max().item()
+            for k in (0, 2, 3):
+                assert bool(torch.isfinite(outs[k]).all())
+                d = (outs[k] - outs[1]).abs().max().item()
                 assert d <= 2e-5 * scale, (nrows, ph, pw, layout, k, d)
+
+
+def test_backward_is_deterministic():
+    """the sparse-matrix gathers have no atomics and a summation order that is a constant of the geometry handle: two calls, same bits"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    B, C, nrows, P, H, W, N = 2, 3, 4, 128, 256, 512, 18
+    gp = torch.rand((B, N, C, P, P), device=DEV)
+    ge = torch.rand((B, C, H, W), device=DEV)
+    outs = []
+    for _ in range(2):
+        e = torch.empty((B, C, H, W), device=DEV); p = torch.empty((B, N, C, P, P), device=DEV)
+        assert lib.omni_equi2pers_bwd(P_(gp), P_(e), 0, B, C, H, W, P, P, nrows, ctypes.c_float(80), ctypes.c_float(80), L.LAYOUT_BNCHW, None) == 0
+        assert lib.omni_pers2equi_bwd(P_(ge), P_(p), 0, B, C, P, P, H, W, nrows, ctypes.c_float(80), ctypes.c_float(80), L.LAYOUT_BNCHW, None) == 0
+        outs.append((e, p))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -1880,7 +1880,15 @@ extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dty
         if (layout == OMNI_LAYOUT_BNCHW) { s.s_sB = (long long)g->N * C * pp; s.s_sC = pp; s.s_hi = (int)(C * pp); s.s_lo = 1; }
         else                             { s.s_sB = (long long)C * pp * g->N; s.s_sC = pp * g->N; s.s_hi = 1; s.s_lo = g->N; }
         s.d_sB = (long long)C * H * W; s.d_sC = (long long)H * W; s.rdiv = 0x7fffffff; s.d_hi = 0; s.d_lo = 1;
-        if ((long long)g->N * C * pp < (1ll << 31)) return sp_apply(g->e2p_sp, s, (hipStream_t)stream);
+        s.PT = (B * C + 3) / 4 * 4; s.nhi = g->N; s.nlo = (int)pp; s.hi_fastest = layout == OMNI_LAYOUT_BCHWN;
+        if ((long long)g->N * C * pp < (1ll << 31)) {
+            float* ws = nullptr;
+            if (omni_options().bwd_wide) {
+                rc = omni_bwd_workspace(const_cast<omni_geometry*>(g), (hipStream_t)stream, (size_t)g->N * pp * s.PT * sizeof(float), &ws);
+                if (rc != OMNI_OK) return rc;
+            }
+            return sp_apply(g->e2p_sp, s, (hipStream_t)stream, ws);
+        }
     }
     // without the table, mode 0: whichever is faster for the layout — measured at B = 8, cfg 1: planar 0.74 ms (LDS boxes + coalesced global atomics) vs
     // 0.88 ms (gathers); reference layout 0.88 ms (gathers) vs 3.17 ms (plain scatter).  3 forces the gathers, 1 the plain scatter, 2 the LDS boxes.

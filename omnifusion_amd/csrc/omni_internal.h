@@ -58,6 +58,7 @@ struct OmniOptions {
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
     int p2e_store;        // OMNI_P2E_STORE      ERP stores of the pers2equi LDS kernels: 1 (default) non-temporal | 0 plain
     int p2e_walk;         // OMNI_P2E_WALK       1 (default): the flat-pipeline kernel p2e_walk_kernel (one stage stream per tile across its patches, stages consumed in pairs) | 0: p2e_lds_kernel (patch by patch)
+    int bwd_wide;         // OMNI_BWD_WIDE       1 (default): the backward gathers read a plane-interleaved copy of the gradient (16-byte gathers) | 0: the gradient itself (4-byte gathers, no scratch)
     int bwd_table_mb;     // OMNI_BWD_TABLE_MB   largest sparse-matrix table of a backward operator kept per geometry, MiB (default 1024; a geometry past it keeps the tile kernels)
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
@@ -99,6 +100,8 @@ struct OmniSpTable {
     long long nent = 0, npadded = 0, nlong_ent = 0;
 };
 void omni_sp_free(OmniSpTable& t);
+struct omni_geometry;
+int omni_bwd_workspace(omni_geometry* g, hipStream_t stream, size_t bytes, float** out);    // omni_geometry.hip
 
 struct omni_geometry {
     int device;
@@ -138,6 +141,10 @@ struct omni_geometry {
     int4* e2p_bwd_box; int* e2p_bwd_ids; int e2p_bwd_nsmall, e2p_bwd_nbig, e2p_gtx, e2p_gty, e2p_bwd_ok;
     // the backward operators as constant sparse matrices (omni_spgather.h): one row per OUTPUT element, entries (source index, weight)
     OmniSpTable p2e_sp, e2p_sp;
+    // scratch of the backward calls (the plane-interleaved copy of the gradient they gather from): one buffer per stream that has called,
+    // grown on demand (never under capture), freed with the handle
+    struct Ws { hipStream_t stream; float* ptr; size_t bytes; };
+    std::vector<Ws> bwd_ws; std::mutex ws_mu;
     // the two backward tables are built by the FIRST backward call of the geometry (3.7 ms of one-time kernels a forward-only user never pays)
     std::mutex bwd_mu; int p2e_bwd_tried = 0, e2p_bwd_tried = 0;
 };

@@ -28,18 +28,19 @@ struct SpApply {
     long long s_sB, s_sC, d_sB, d_sC;     // element strides of batch / channel in source and destination
     int s_hi, s_lo;                       // source offset inside a plane: (e.x >> 24) * s_hi + (e.x & 0xffffff) * s_lo
     int rdiv; long long d_hi; int d_lo;   // destination offset of row r inside a plane: (r / rdiv) * d_hi + (r % rdiv) * d_lo
+    // the plane-interleaved copy of the source (sp_interleave_kernel): record (hi, lo) = PT consecutive floats, one per plane (padded to a multiple of 4)
+    const float* ws; int PT; int nhi, nlo, hi_fastest;   // record index = hi_fastest ? lo * nhi + hi : hi * nlo + lo  (the order the source itself is contiguous in)
 };
 
-// One wave per slice of 64 rows, PL planes in registers.
+// One wave per slice of 64 rows, PL planes in registers; the blocks past the slices take one long row each (fixed partition of its entries
+// over the 256 threads and a fixed reduction tree: deterministic).  A slice's entries are consumed four at a time: the four table loads,
+// then their 4 x PL gathers, are all in flight together (a chain of dependent round trips otherwise: 110 -> 60 us for pers2equi^T);
+// a padding slot gathers element 0 and contributes nothing (its VALUE is masked, not its weight: a non-finite gradient at element 0 stays where it is).
+constexpr unsigned SP_CH = 16;
 template <int PL>
-__global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s)
+__global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_blocks)
 {
-    const int lane = threadIdx.x & 63;
-    const int slice = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (slice >= s.nslices) return;
-    const int row = slice * 64 + lane, p0 = blockIdx.y * PL;
-    const int o0 = s.slice_off[slice], K = s.slice_off[slice + 1] - o0;
-    const int nk = row < s.nrows ? s.cnt[row] : -1;
+    const int lane = threadIdx.x & 63, p0 = blockIdx.y * PL;
     const float* sp[PL];
 #pragma unroll
     for (int p = 0; p < PL; ++p) {
@@ -49,61 +50,190 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s)
     float acc[PL];
 #pragma unroll
     for (int p = 0; p < PL; ++p) acc[p] = 0.0f;
-    const uint2* e = s.ent + (size_t)o0 * 64 + lane;
-#pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-        const uint2 en = e[(size_t)k * 64];
-        if (k < nk) {
+
+    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- a long row
+        __shared__ float part[4][PL];
+        const int lr = blockIdx.x - nslice_blocks, wave = threadIdx.x >> 6;
+        const int row = s.long_row[lr], o0 = s.long_off[lr], o1 = s.long_off[lr + 1];
+        for (int i = o0 + (int)threadIdx.x; i < o1; i += 256) {
+            const uint2 en = s.long_ent[i];
             const int off = (int)(en.x >> 24) * s.s_hi + (int)(en.x & 0xffffffu) * s.s_lo;
             const float w = __uint_as_float(en.y);
 #pragma unroll
             for (int p = 0; p < PL; ++p) acc[p] = fmaf(sp[p][off], w, acc[p]);
         }
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            float v = acc[p];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) part[wave][p] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < PL && p0 + (int)threadIdx.x < s.planes) {
+            const int p = threadIdx.x;
+            const float v = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
+            const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
+            s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
+        }
+        return;
     }
-    if (nk < 0) return;                                           // past the end, or a long row (sp_long_kernel writes it)
+
+    // (hardware block b runs on XCD b % 8: every XCD gets one contiguous range of slices, so neighbouring rows — which gather the same
+    //  source lines — share one L2; in chunks of SP_CH blocks dealt round-robin, because the rows near a pole are the expensive ones)
+    unsigned lb = blockIdx.x;
+    {
+        const unsigned span = 8u * SP_CH, full = (unsigned)nslice_blocks / span * span;
+        if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / SP_CH) * 8u + x) * SP_CH + q % SP_CH; }
+    }
+    const int slice = __builtin_amdgcn_readfirstlane((int)(lb * 4 + (threadIdx.x >> 6)));
+    if (slice >= s.nslices) return;
+    const int row = slice * 64 + lane;
+    const int o0 = s.slice_off[slice], K = s.slice_off[slice + 1] - o0;
+    const int nk = row < s.nrows ? s.cnt[row] : -1;
+    const uint2* e = s.ent + (size_t)o0 * 64 + lane;
+    constexpr int U = 4;
+    for (int k0 = 0; k0 < K; k0 += U) {
+        uint2 en[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) en[u] = k0 + u < K ? e[(size_t)(k0 + u) * 64] : make_uint2(0u, 0u);     // (K is wave-uniform)
+        float v[U][PL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int off = (int)(en[u].x >> 24) * s.s_hi + (int)(en[u].x & 0xffffffu) * s.s_lo;
+#pragma unroll
+            for (int p = 0; p < PL; ++p) v[u][p] = sp[p][off];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool real = k0 + u < nk;
+            const float w = __uint_as_float(en[u].y);
+#pragma unroll
+            for (int p = 0; p < PL; ++p) acc[p] = fmaf(real ? v[u][p] : 0.0f, w, acc[p]);
+        }
+    }
+    if (nk < 0) return;                                           // past the end, or a long row
     const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
 #pragma unroll
     for (int p = 0; p < PL; ++p)
         if (p0 + p < s.planes) s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = acc[p];
 }
 
-// One block of 256 threads per long row (fixed partition of the entries and fixed reduction tree: deterministic).
-template <int PL>
-__global__ __launch_bounds__(256) void sp_long_kernel(SpApply s)
+// ---- the same through a plane-interleaved copy of the source.  A 4-byte gather costs the texture path one tag look-up per lane quad and
+// line whatever it returns (measured: 28 L1 accesses per wave-level gather, the L1 busy 60 % of the 90 us of pers2equi^T): with the PT planes of
+// a source element side by side, ONE 16-byte gather per entry and four planes replaces four.  The copy is one coalesced pass (LDS transposition).
+constexpr int SP_ICH = 24;                                         // planes per block of the interleave kernel
+__global__ __launch_bounds__(256) void sp_interleave_kernel(SpApply s, float* __restrict__ ws, int R)
 {
-    __shared__ float part[4][PL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = s.long_row[blockIdx.x], o0 = s.long_off[blockIdx.x], o1 = s.long_off[blockIdx.x + 1], p0 = blockIdx.y * PL;
-    const float* sp[PL];
-#pragma unroll
-    for (int p = 0; p < PL; ++p) {
-        const int pl = min(p0 + p, s.planes - 1);
-        sp[p] = s.src + (size_t)(pl / s.C) * s.s_sB + (size_t)(pl % s.C) * s.s_sC;
-    }
-    float acc[PL];
-#pragma unroll
-    for (int p = 0; p < PL; ++p) acc[p] = 0.0f;
-    for (int i = o0 + (int)threadIdx.x; i < o1; i += 256) {
-        const uint2 en = s.long_ent[i];
-        const int off = (int)(en.x >> 24) * s.s_hi + (int)(en.x & 0xffffffu) * s.s_lo;
-        const float w = __uint_as_float(en.y);
-#pragma unroll
-        for (int p = 0; p < PL; ++p) acc[p] = fmaf(sp[p][off], w, acc[p]);
-    }
-#pragma unroll
-    for (int p = 0; p < PL; ++p) {
-        float v = acc[p];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        if (lane == 0) part[wave][p] = v;
+    __shared__ float tile[256 * (SP_ICH + 1)];
+    constexpr int PP = SP_ICH + 1;
+    const int t = threadIdx.x, rec0 = blockIdx.x * 256, rec = rec0 + t, c0 = blockIdx.y * SP_ICH;
+    const int wc = min(SP_ICH, s.PT - c0), nrec = min(256, R - rec0);
+    if (rec < R) {
+        int hi, lo;
+        if (s.hi_fastest) { lo = rec / s.nhi; hi = rec - lo * s.nhi; } else { hi = rec / s.nlo; lo = rec - hi * s.nlo; }
+        const size_t off = (size_t)hi * s.s_hi + (size_t)lo * s.s_lo;
+        for (int p = 0; p < wc; ++p) {
+            const int pl = c0 + p;
+            tile[t * PP + p] = pl < s.planes ? s.src[(size_t)(pl / s.C) * s.s_sB + (size_t)(pl % s.C) * s.s_sC + off] : 0.0f;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < PL && p0 + (int)threadIdx.x < s.planes) {
-        const int p = threadIdx.x;
-        const float v = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
-        const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
-        s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
+    const int q = wc >> 2;                                         // 16-byte pieces per record
+    for (int i = t; i < nrec * q; i += 256) {
+        const int r = i / q, p = (i - r * q) * 4;
+        const float* tp = tile + r * PP + p;
+        *reinterpret_cast<float4*>(ws + (size_t)(rec0 + r) * s.PT + c0 + p) = make_float4(tp[0], tp[1], tp[2], tp[3]);
     }
+}
+
+template <int PG>                                                  // planes per pass (a multiple of 4)
+__global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nslice_blocks)
+{
+    constexpr int Q = PG / 4;
+    const int lane = threadIdx.x & 63, p0 = blockIdx.y * PG;
+    const int r_hi = s.hi_fastest ? 1 : s.nlo, r_lo = s.hi_fastest ? s.nhi : 1;
+    const float* wsp = s.ws + p0;
+    float acc[PG];
+#pragma unroll
+    for (int p = 0; p < PG; ++p) acc[p] = 0.0f;
+    auto rec_ptr = [&](unsigned src) {
+        return reinterpret_cast<const float4*>(wsp + (size_t)((int)(src >> 24) * r_hi + (int)(src & 0xffffffu) * r_lo) * s.PT);
+    };
+
+    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- a long row
+        __shared__ float part[4][PG];
+        const int lr = blockIdx.x - nslice_blocks, wave = threadIdx.x >> 6;
+        const int row = s.long_row[lr], o0 = s.long_off[lr], o1 = s.long_off[lr + 1];
+        for (int i = o0 + (int)threadIdx.x; i < o1; i += 256) {
+            const uint2 en = s.long_ent[i];
+            const float4* rp = rec_ptr(en.x);
+            const float w = __uint_as_float(en.y);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float4 v = rp[q];
+                acc[4 * q] = fmaf(v.x, w, acc[4 * q]); acc[4 * q + 1] = fmaf(v.y, w, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(v.z, w, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v.w, w, acc[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PG; ++p) {
+            float v = acc[p];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) part[wave][p] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < PG && p0 + (int)threadIdx.x < s.planes) {
+            const int p = threadIdx.x;
+            const float v = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
+            const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
+            s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
+        }
+        return;
+    }
+
+    unsigned lb = blockIdx.x;                                      // (XCD map as in sp_gather_kernel)
+    {
+        const unsigned span = 8u * SP_CH, full = (unsigned)nslice_blocks / span * span;
+        if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / SP_CH) * 8u + x) * SP_CH + q % SP_CH; }
+    }
+    const int slice = __builtin_amdgcn_readfirstlane((int)(lb * 4 + (threadIdx.x >> 6)));
+    if (slice >= s.nslices) return;
+    const int row = slice * 64 + lane;
+    const int o0 = s.slice_off[slice], K = s.slice_off[slice + 1] - o0;
+    const int nk = row < s.nrows ? s.cnt[row] : -1;
+    const uint2* e = s.ent + (size_t)o0 * 64 + lane;
+    constexpr int U = 4;
+    for (int k0 = 0; k0 < K; k0 += U) {
+        uint2 en[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) en[u] = k0 + u < K ? e[(size_t)(k0 + u) * 64] : make_uint2(0u, 0u);     // (K is wave-uniform)
+        float4 v[U][Q];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4* rp = rec_ptr(en[u].x);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) v[u][q] = rp[q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool real = k0 + u < nk;
+            const float w = __uint_as_float(en[u].y);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                acc[4 * q]     = fmaf(real ? v[u][q].x : 0.0f, w, acc[4 * q]);
+                acc[4 * q + 1] = fmaf(real ? v[u][q].y : 0.0f, w, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(real ? v[u][q].z : 0.0f, w, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(real ? v[u][q].w : 0.0f, w, acc[4 * q + 3]);
+            }
+        }
+    }
+    if (nk < 0) return;                                           // past the end, or a long row
+    const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
+#pragma unroll
+    for (int p = 0; p < PG; ++p)
+        if (p0 + p < s.planes) s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = acc[p];
 }
 
 // ---- building a table.  The operator's own file walks its taps twice with sp_emit: pass 0 counts the entries of every row, pass 1 deposits
@@ -213,21 +343,28 @@ struct SpBuilder {
     }
 };
 
-// launch: planes in groups of 8 (12 where the plane count is a multiple of 12: three-channel images)
-inline int sp_apply(const OmniSpTable& t, SpApply s, hipStream_t stream)
+// launch.  ws != null: through the plane-interleaved copy (ws holds nhi * nlo records of s.PT floats); else 4-byte gathers from the source
+// itself, planes in groups of 8 (12 where the plane count is a multiple of 12).  The long rows ride in the same grid.
+inline int sp_apply(const OmniSpTable& t, SpApply s, hipStream_t stream, float* ws)
 {
     s.ent = t.ent; s.slice_off = t.slice_off; s.cnt = t.cnt; s.nrows = t.nrows; s.nslices = t.nslices;
     s.long_ent = t.long_ent; s.long_off = t.long_off; s.long_row = t.long_row;
-    const unsigned nb = (unsigned)((t.nslices + 3) / 4);
-    if (s.planes > 8 && s.planes % 12 == 0) {
-        const unsigned groups = (unsigned)(s.planes / 12);
-        if (t.nlong) hipLaunchKernelGGL(sp_long_kernel<12>, dim3((unsigned)t.nlong, groups), dim3(256), 0, stream, s);
-        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3(nb, groups), dim3(256), 0, stream, s);
-    } else {
-        const unsigned groups = (unsigned)((s.planes + 7) / 8);
-        if (t.nlong) hipLaunchKernelGGL(sp_long_kernel<8>, dim3((unsigned)t.nlong, groups), dim3(256), 0, stream, s);
-        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3(nb, groups), dim3(256), 0, stream, s);
+    const int nb = (t.nslices + 3) / 4;
+    if (ws) {
+        const int R = s.nhi * s.nlo;
+        s.ws = ws;
+        hipLaunchKernelGGL(sp_interleave_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)((s.PT + SP_ICH - 1) / SP_ICH)), dim3(256), 0, stream, s, ws, R);
+        if (s.PT % 12 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nb);
+        else if (s.PT % 8 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<8>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 8)), dim3(256), 0, stream, s, nb);
+        else                    hipLaunchKernelGGL(sp_gather_wide_kernel<4>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 4)), dim3(256), 0, stream, s, nb);
+        OMNI_HIP(hipGetLastError());
+        return OMNI_OK;
     }
+    s.ws = nullptr;
+    if (s.planes > 8 && s.planes % 12 == 0)
+        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.planes / 12)), dim3(256), 0, stream, s, nb);
+    else
+        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3((unsigned)(nb + t.nlong), (unsigned)((s.planes + 7) / 8)), dim3(256), 0, stream, s, nb);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

@@ -100,16 +100,17 @@ def test_pers2equi_backward_gather_equals_scatter():
         ge = torch.rand((B, C, H, W), device=DEV)
         outs = []
         try:
-            for simple in (0, 1, 2):
-                L.set_option("p2e_bwd_simple", simple)
+            for simple, wide in ((0, 1), (1, 1), (2, 1), (0, 0)):       # (wide: through the plane-interleaved copy of the gradient | 4-byte gathers)
+                L.set_option("p2e_bwd_simple", simple); L.set_option("bwd_wide", wide)
                 gp = torch.full((B, N, C, ph, pw), float("nan"), device=DEV)
                 rc = lib.omni_pers2equi_bwd(P_(ge), P_(gp), 0, B, C, ph, pw, H, W, nrows, ctypes.c_float(80), ctypes.c_float(80), L.LAYOUT_BNCHW, None)
                 assert rc == 0, lib.omni_last_error()
                 outs.append(gp)
         finally:
-            L.set_option("p2e_bwd_simple", 0)
+            L.set_option("p2e_bwd_simple", 0); L.set_option("bwd_wide", 1)
         torch.cuda.synchronize()
-        assert bool(torch.isfinite(outs[0]).all()) and bool(torch.isfinite(outs[2]).all())
+        assert all(bool(torch.isfinite(o).all()) for o in outs)
+        assert torch.equal(outs[0], outs[3]), "the interleaved copy changes no bit"
         for k in (0, 2):
             d = (outs[k] - outs[1]).abs().max().item()
             assert d <= 1e-5 * max(1.0, outs[1].abs().max().item()), (nrows, ph, pw, k, d)
@@ -129,15 +130,16 @@ def test_equi2pers_backward_gather_equals_scatter():
             gp = torch.rand((B, N, C, ph, pw) if layout == L.LAYOUT_BNCHW else (B, C, ph, pw, N), device=DEV)
             outs = []
             try:
-                for mode in (4, 1, 2, 3):
-                    L.set_option("e2p_bwd_simple", mode)
+                for mode, wide in ((4, 1), (1, 1), (2, 1), (3, 1), (4, 0)):
+                    L.set_option("e2p_bwd_simple", mode); L.set_option("bwd_wide", wide)
                     ge = torch.full((B, C, H, W), float("nan"), device=DEV)
                     rc = lib.omni_equi2pers_bwd(P_(gp), P_(ge), 0, B, C, H, W, ph, pw, nrows, ctypes.c_float(80), ctypes.c_float(80), layout, None)
                     assert rc == 0, lib.omni_last_error()
                     outs.append(ge)
             finally:
-                L.set_option("e2p_bwd_simple", 0)
+                L.set_option("e2p_bwd_simple", 0); L.set_option("bwd_wide", 1)
             torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[4]), "the interleaved copy changes no bit"
             assert bool(torch.isfinite(outs[0]).all())
             scale = max(1.0, outs[1].abs().max().item())
             for k in (0, 2, 3):

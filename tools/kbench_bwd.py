@@ -13,7 +13,9 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
-for lay, name in ((L.LAYOUT_BNCHW, "planar"), (L.LAYOUT_BCHWN, "reference")):
+LAYOUTS = ((L.LAYOUT_BNCHW, "planar"), (L.LAYOUT_BCHWN, "reference"))
+if os.environ.get("LAYOUT"): LAYOUTS = tuple(l for l in LAYOUTS if l[1] == os.environ["LAYOUT"])
+for lay, name in LAYOUTS:
     gp = torch.rand((B, N, 3, P, P) if lay == L.LAYOUT_BNCHW else (B, 3, P, P, N), device="cuda")
     ge = torch.empty((B, 3, H, W), device="cuda")
     t1 = timeit(lambda: lib.omni_equi2pers_bwd(P_(gp), P_(ge), 0, B, 3, H, W, P, P, nrows, ctypes.c_float(80), ctypes.c_float(80), lay, None))

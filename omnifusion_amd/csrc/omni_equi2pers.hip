@@ -1880,7 +1880,7 @@ extern "C" int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dty
         if (layout == OMNI_LAYOUT_BNCHW) { s.s_sB = (long long)g->N * C * pp; s.s_sC = pp; s.s_hi = (int)(C * pp); s.s_lo = 1; }
         else                             { s.s_sB = (long long)C * pp * g->N; s.s_sC = pp * g->N; s.s_hi = 1; s.s_lo = g->N; }
         s.d_sB = (long long)C * H * W; s.d_sC = (long long)H * W; s.rdiv = 0x7fffffff; s.d_hi = 0; s.d_lo = 1;
-        s.PT = (B * C + 3) / 4 * 4; s.nhi = g->N; s.nlo = (int)pp; s.hi_fastest = layout == OMNI_LAYOUT_BCHWN;
+        s.PT = (B * C + 3) / 4 * 4; s.nhi = g->N; s.nlo = (int)pp; s.hi_fastest = layout == OMNI_LAYOUT_BCHWN; s.chunk = 16;
         if ((long long)g->N * C * pp < (1ll << 31)) {
             float* ws = nullptr;
             if (omni_options().bwd_wide) {

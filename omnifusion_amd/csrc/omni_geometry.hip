@@ -41,6 +41,7 @@ const OptName kOpts[] = {
     {"p2e_bwd_simple", "OMNI_P2E_BWD_SIMPLE", &OmniOptions::p2e_bwd_simple, 0},
     {"bwd_table_mb", "OMNI_BWD_TABLE_MB", &OmniOptions::bwd_table_mb, 1024},
     {"bwd_wide", "OMNI_BWD_WIDE", &OmniOptions::bwd_wide, 1},
+    {"bwd_chunk", "OMNI_BWD_CHUNK", &OmniOptions::bwd_chunk, 0},
     {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
     {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},
     {"e2p_slot_kb", "OMNI_E2P_SLOT_KB", &OmniOptions::e2p_slot_kb, 6},
@@ -235,16 +236,20 @@ extern "C" int omni_geometry_create(omni_geometry_t** out, int nrows, float fov_
 }
 
 // The calling stream's scratch buffer of at least `bytes` (stream-ordered use: a buffer is only ever touched by launches on its own stream).
+// A handle that has been used under stream capture keeps every buffer it ever handed out (a graph may hold the pointer).
 int omni_bwd_workspace(omni_geometry* g, hipStream_t stream, size_t bytes, float** out)
 {
     std::lock_guard<std::mutex> lk(g->ws_mu);
     omni_geometry::Ws* w = nullptr;
-    for (auto& x : g->bwd_ws) if (x.stream == stream) { w = &x; break; }
-    if (w && w->bytes >= bytes) { *out = w->ptr; return OMNI_OK; }
+    for (auto& x : g->bwd_ws)
+        if (x.stream == stream) {
+            if (x.bytes >= bytes) { *out = x.ptr; return OMNI_OK; }
+            w = &x;
+        }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
         OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "backward: first use of a batch size on this geometry and stream while the stream is being captured (run the shape once before capturing)");
-    if (!w) { g->bwd_ws.push_back({stream, nullptr, 0}); w = &g->bwd_ws.back(); }
+    if (!w || g->pinned) { g->bwd_ws.push_back({stream, nullptr, 0}); w = &g->bwd_ws.back(); }
     if (w->ptr) { OMNI_HIP(hipStreamSynchronize(stream)); OMNI_HIP(hipFree(w->ptr)); w->ptr = nullptr; w->bytes = 0; }
     OMNI_HIP(hipMalloc((void**)&w->ptr, bytes));
     w->bytes = bytes; *out = w->ptr;

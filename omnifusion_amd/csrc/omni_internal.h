@@ -59,6 +59,7 @@ struct OmniOptions {
     int p2e_store;        // OMNI_P2E_STORE      ERP stores of the pers2equi LDS kernels: 1 (default) non-temporal | 0 plain
     int p2e_walk;         // OMNI_P2E_WALK       1 (default): the flat-pipeline kernel p2e_walk_kernel (one stage stream per tile across its patches, stages consumed in pairs) | 0: p2e_lds_kernel (patch by patch)
     int bwd_wide;         // OMNI_BWD_WIDE       1 (default): the backward gathers read a plane-interleaved copy of the gradient (16-byte gathers) | 0: the gradient itself (4-byte gathers, no scratch)
+    int bwd_chunk;        // OMNI_BWD_CHUNK      blocks per XCD chunk of the backward gathers (0: 16; 4 .. 64 measured within 3 %)
     int bwd_table_mb;     // OMNI_BWD_TABLE_MB   largest sparse-matrix table of a backward operator kept per geometry, MiB (default 1024; a geometry past it keeps the tile kernels)
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };

@@ -1495,7 +1495,7 @@ extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dty
         s.src = (const float*)grad_erp; s.dst = (float*)grad_pers; s.C = C; s.planes = B * C;
         s.s_sB = (long long)C * H * W; s.s_sC = (long long)H * W; s.s_hi = 0; s.s_lo = 1;
         s.d_sB = a.sB; s.d_sC = a.sC; s.rdiv = ph * pw; s.d_hi = a.sN; s.d_lo = (int)a.sX;
-        s.PT = (B * C + 3) / 4 * 4; s.nhi = 1; s.nlo = H * W; s.hi_fastest = 0;
+        s.PT = (B * C + 3) / 4 * 4; s.nhi = 1; s.nlo = H * W; s.hi_fastest = 0; s.chunk = 16;
         float* ws = nullptr;
         if (omni_options().bwd_wide) {
             rc = omni_bwd_workspace(const_cast<omni_geometry*>(g), (hipStream_t)stream, (size_t)H * W * s.PT * sizeof(float), &ws);

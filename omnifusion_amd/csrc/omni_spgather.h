@@ -29,6 +29,7 @@ struct SpApply {
     int s_hi, s_lo;                       // source offset inside a plane: (e.x >> 24) * s_hi + (e.x & 0xffffff) * s_lo
     int rdiv; long long d_hi; int d_lo;   // destination offset of row r inside a plane: (r / rdiv) * d_hi + (r % rdiv) * d_lo
     // the plane-interleaved copy of the source (sp_interleave_kernel): record (hi, lo) = PT consecutive floats, one per plane (padded to a multiple of 4)
+    int chunk;                            // blocks (of 4 slices) per XCD chunk
     const float* ws; int PT; int nhi, nlo, hi_fastest;   // record index = hi_fastest ? lo * nhi + hi : hi * nlo + lo  (the order the source itself is contiguous in)
 };
 
@@ -36,7 +37,6 @@ struct SpApply {
 // over the 256 threads and a fixed reduction tree: deterministic).  A slice's entries are consumed four at a time: the four table loads,
 // then their 4 x PL gathers, are all in flight together (a chain of dependent round trips otherwise: 110 -> 60 us for pers2equi^T);
 // a padding slot gathers element 0 and contributes nothing (its VALUE is masked, not its weight: a non-finite gradient at element 0 stays where it is).
-constexpr unsigned SP_CH = 16;
 template <int PL>
 __global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_blocks)
 {
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_bl
     }
 
     // (hardware block b runs on XCD b % 8: every XCD gets one contiguous range of slices, so neighbouring rows — which gather the same
-    //  source lines — share one L2; in chunks of SP_CH blocks dealt round-robin, because the rows near a pole are the expensive ones)
+    //  source lines — share one L2; in chunks of s.chunk blocks dealt round-robin, because the rows near a pole are the expensive ones)
     unsigned lb = blockIdx.x;
     {
-        const unsigned span = 8u * SP_CH, full = (unsigned)nslice_blocks / span * span;
-        if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / SP_CH) * 8u + x) * SP_CH + q % SP_CH; }
+        const unsigned ch = (unsigned)s.chunk, span = 8u * ch, full = (unsigned)nslice_blocks / span * span;
+        if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / ch) * 8u + x) * ch + q % ch; }
     }
     const int slice = __builtin_amdgcn_readfirstlane((int)(lb * 4 + (threadIdx.x >> 6)));
     if (slice >= s.nslices) return;
@@ -133,9 +133,15 @@ __global__ __launch_bounds__(256) void sp_interleave_kernel(SpApply s, float* __
         int hi, lo;
         if (s.hi_fastest) { lo = rec / s.nhi; hi = rec - lo * s.nhi; } else { hi = rec / s.nlo; lo = rec - hi * s.nlo; }
         const size_t off = (size_t)hi * s.s_hi + (size_t)lo * s.s_lo;
-        for (int p = 0; p < wc; ++p) {
-            const int pl = c0 + p;
-            tile[t * PP + p] = pl < s.planes ? s.src[(size_t)(pl / s.C) * s.s_sB + (size_t)(pl % s.C) * s.s_sC + off] : 0.0f;
+        for (int p4 = 0; p4 < wc; p4 += 4) {                      // (four independent loads in flight, then their LDS writes)
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pl = c0 + p4 + u;
+                v[u] = pl < s.planes ? s.src[(size_t)(pl / s.C) * s.s_sB + (size_t)(pl % s.C) * s.s_sC + off] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tile[t * PP + p4 + u] = v[u];
         }
     }
     __syncthreads();
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
 
     unsigned lb = blockIdx.x;                                      // (XCD map as in sp_gather_kernel)
     {
-        const unsigned span = 8u * SP_CH, full = (unsigned)nslice_blocks / span * span;
-        if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / SP_CH) * 8u + x) * SP_CH + q % SP_CH; }
+        const unsigned ch = (unsigned)s.chunk, span = 8u * ch, full = (unsigned)nslice_blocks / span * span;
+        if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / ch) * 8u + x) * ch + q % ch; }
     }
     const int slice = __builtin_amdgcn_readfirstlane((int)(lb * 4 + (threadIdx.x >> 6)));
     if (slice >= s.nslices) return;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
     const int o0 = s.slice_off[slice], K = s.slice_off[slice + 1] - o0;
     const int nk = row < s.nrows ? s.cnt[row] : -1;
     const uint2* e = s.ent + (size_t)o0 * 64 + lane;
-    constexpr int U = 4;
+    constexpr int U = PG >= 16 ? 2 : 4;
     for (int k0 = 0; k0 < K; k0 += U) {
         uint2 en[U];
 #pragma unroll
@@ -350,11 +356,14 @@ inline int sp_apply(const OmniSpTable& t, SpApply s, hipStream_t stream, float* 
     s.ent = t.ent; s.slice_off = t.slice_off; s.cnt = t.cnt; s.nrows = t.nrows; s.nslices = t.nslices;
     s.long_ent = t.long_ent; s.long_off = t.long_off; s.long_row = t.long_row;
     const int nb = (t.nslices + 3) / 4;
+    if (omni_options().bwd_chunk > 0) s.chunk = omni_options().bwd_chunk;
     if (ws) {
         const int R = s.nhi * s.nlo;
         s.ws = ws;
         hipLaunchKernelGGL(sp_interleave_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)((s.PT + SP_ICH - 1) / SP_ICH)), dim3(256), 0, stream, s, ws, R);
-        if (s.PT % 12 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nb);
+        if (s.PT % 24 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<24>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 24)), dim3(256), 0, stream, s, nb);
+        else if (s.PT % 16 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<16>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 16)), dim3(256), 0, stream, s, nb);
+        else if (s.PT % 12 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nb);
         else if (s.PT % 8 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<8>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 8)), dim3(256), 0, stream, s, nb);
         else                    hipLaunchKernelGGL(sp_gather_wide_kernel<4>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 4)), dim3(256), 0, stream, s, nb);
         OMNI_HIP(hipGetLastError());

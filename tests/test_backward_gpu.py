@@ -165,3 +165,48 @@ def test_backward_is_deterministic():
         outs.append((e, p))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_backward_under_capture_keeps_its_scratch():
+    """the backward gathers read a plane-interleaved copy of the gradient held in a per-(geometry, stream) scratch buffer: a batch size first
+    seen while the stream is being captured is refused (the buffer would have to be allocated), and a larger eager batch later on the same
+    stream does not free the buffer a captured graph replays from"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    lib.omni_geometry_cache_clear()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    nrows, P, H, W, N = 4, 32, 64, 128, 18
+    f80 = ctypes.c_float(80)
+    s = torch.cuda.Stream()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    def both(B, ge, gp, oe, op, stream):
+        rc1 = lib.omni_equi2pers_bwd(P_(gp), P_(oe), 0, B, 1, H, W, P, P, nrows, f80, f80, L.LAYOUT_BNCHW, stream)
+        rc2 = lib.omni_pers2equi_bwd(P_(ge), P_(op), 0, B, 1, P, P, H, W, nrows, f80, f80, L.LAYOUT_BNCHW, stream)
+        return rc1, rc2
+    mk = lambda B: (torch.rand((B, 1, H, W), device=DEV), torch.rand((B, N, 1, P, P), device=DEV),
+                    torch.zeros((B, 1, H, W), device=DEV), torch.zeros((B, N, 1, P, P), device=DEV))
+    t2 = mk(2)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        assert both(2, *t2, sp) == (0, 0)                              # warms tables and the stream's scratch
+    s.synchronize()
+    want = (t2[2].clone(), t2[3].clone())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        assert both(2, *t2, sp) == (0, 0)
+    t8 = mk(8)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        rcs = both(8, *t8, sp)
+    # (equi2pers^T needs 4x its warm-up scratch; pers2equi^T at this size still fits the buffer the stream already owns: both use the same one)
+    assert rcs[0] != 0 and rcs[1] == 0 and b"captured" in lib.omni_last_error()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        assert both(8, *t8, sp) == (0, 0)                              # a larger scratch for the same stream; the graph's stays
+    s.synchronize()
+    t2[2].zero_(); t2[3].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(t2[2], want[0]) and torch.equal(t2[3], want[1])
+    lib.omni_geometry_cache_clear()

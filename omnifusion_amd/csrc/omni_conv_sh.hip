@@ -151,7 +151,7 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
         }
 }
 
-// The same epilogue through LDS, for SH outputs (and SH or no residual, no `post`): a wave's NT accumulator tiles of 32 CONSECUTIVE pixel rows
+// The same epilogue through LDS, for SH outputs (and SH or no residual): a wave's NT accumulator tiles of 32 CONSECUTIVE pixel rows
 // r0 .. r0+31 go to a wave-private [32][32 NT + 4] float tile and come back as (pixel, 32-channel group, 8-channel piece) tasks, four
 // consecutive lanes per pixel group: the residual arrives and the result leaves as 16-byte pieces, 64 contiguous bytes per pixel and
 // half (hi | lo) per instruction.  epilogue_row moves 8 bytes per lane, 16 per pixel and instruction — 4.7 M sixteen-byte requests for
@@ -178,7 +178,7 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (wave-private tile: the wave's own writes have landed)
     constexpr int TASKS = 32 * NT * 4 / 64;                       // (pixel, group, piece) tasks per lane
-    f4v va[TASKS], vb[TASKS]; h8v rh[TASKS], rl[TASKS];
+    f4v va[TASKS], vb[TASKS], pa[TASKS], pb[TASKS]; h8v rh[TASKS], rl[TASKS];
     size_t off[TASKS]; bool ok[TASKS];
 #pragma unroll
     for (int k = 0; k < TASKS; ++k) {
@@ -191,6 +191,10 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
         if (a.res && ok[k]) {
             rh[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k]);
             rl[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k] + 64);
+        }
+        if (a.post && ok[k]) {                                    // added AFTER the activation, as in epilogue_row
+            const float* pp = a.post + (size_t)((unsigned)(px < 16 ? r0 + px : r1 + (px - 16)) % a.post_rows) * a.Cout + c0[j] + 8 * pc;
+            pa[k] = *reinterpret_cast<const f4v*>(pp); pb[k] = *reinterpret_cast<const f4v*>(pp + 4);
         }
     }
 #pragma unroll
@@ -208,6 +212,7 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = 0.5f * v0[e] * (1.0f + erff(v0[e] * 0.70710678118654752440f)); v1[e] = 0.5f * v1[e] * (1.0f + erff(v1[e] * 0.70710678118654752440f)); }
         }
+        if (a.post) { v0 += pa[k]; v1 += pb[k]; }
         h4v h0, l0, h1, l1;
         sh_split4(v0, h0, l0); sh_split4(v1, h1, l1);
         h8v oh, ol;
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
 
     if (OMNI_ABL(4) || OMNI_DBG(a, 4)) return;
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
-    if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {       // split-half output: through LDS, 16-byte pieces (epilogue_tile_lds)
+    if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {       // (`post`: only the halo kernel takes it through LDS — the registers it costs would spill here) split-half output: through LDS, 16-byte pieces (epilogue_tile_lds)
         static_assert(NW * 32 * (32 * TN + 4) * 4 <= NST * STAGE, "the transposition tiles must fit the K loop's buffers");
         wait_lds_reads();
         __syncthreads();                                          // every wave is done with the last stage
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
     int c0[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) c0[j] = col0 + j * 32;
-    if (a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {
+    if (a.dst_sh && !a.res_f32 && a.epi_lds) {
         static_assert(TH * 32 * (32 * TN + 4) * 4 <= (int)sizeof(lds), "the transposition tiles must fit the K loop's buffers");
         wait_lds_reads();
         __syncthreads();                                          // every wave is done with the halo and the weights

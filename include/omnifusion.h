@@ -136,7 +136,10 @@ enum omni_act { OMNI_ACT_NONE = 0, OMNI_ACT_RELU = 1, OMNI_ACT_GELU = 2 };
 /* Backward of the two operators: the vector-Jacobian products that autograd derives from
  * F.grid_sample (equi_pers/equi2pers_v3.py:111) and from the indexing gathers of equi_pers/pers2equi_v3.py:174-196 in the
  * reference's training scripts (train_erp_depth.py:255-300).  Both operators are linear in the image.  fp32 only; the output
- * gradient is overwritten; layouts as in the forward (grad_pers: OMNI_LAYOUT_BCHWN or _BNCHW). */
+ * gradient is overwritten; layouts as in the forward (grad_pers: OMNI_LAYOUT_BCHWN or _BNCHW).  No atomics: the result of a call is
+ * a function of its inputs and the geometry handle only (fixed summation order).  The first backward of a geometry builds its tables
+ * (synchronises the stream once); the first call of a (geometry, stream, B * C) allocates scratch the size of the incoming gradient
+ * — OMNI_ERR_UNSUPPORTED if that first call happens while the stream is being captured (run the shape once before capturing). */
 int omni_equi2pers_bwd(const void* grad_pers, void* grad_erp, int dtype, int B, int C, int H, int W,
                        int ph, int pw, int nrows, float fov_h, float fov_w, int layout, omni_stream_t stream);
 int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dtype, int B, int C, int ph, int pw,

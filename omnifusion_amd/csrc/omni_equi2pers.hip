@@ -1829,13 +1829,13 @@ int omni_e2p_build_bwd(omni_geometry* g, hipStream_t stream)
     // the sparse-matrix form (the default): rows = ERP pixels, sources = patch samples (patch in the high 8 bits, sample in the low 24)
     if ((long long)g->H * g->W < (1ll << 31) && (long long)g->ph * g->pw <= (1ll << 24) && g->N < 256) {
         SpBuilder sb;
-        int rc = sb.begin(&g->e2p_sp, g->H * g->W);
+        int rc = sb.begin(&g->e2p_sp, g->H * g->W, stream);
         if (rc != OMNI_OK) return rc;
         hipLaunchKernelGGL(e2p_sp_walk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, (int)total, sb.emit(0));
         OMNI_HIP(hipGetLastError());
         OMNI_HIP(hipStreamSynchronize(stream));
         bool fits = false;
-        rc = sb.layout((size_t)omni_options().bwd_table_mb << 20, &fits);
+        rc = sb.layout((size_t)omni_options().bwd_table_mb << 20, &fits, stream);
         if (rc != OMNI_OK) return rc;
         if (fits) {
             hipLaunchKernelGGL(e2p_sp_walk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, (int)total, sb.emit(1));

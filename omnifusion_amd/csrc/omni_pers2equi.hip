@@ -1445,13 +1445,13 @@ int omni_p2e_build_bwd(omni_geometry* g, hipStream_t stream)
     const long long nrows = (long long)g->N * g->ph * g->pw;
     if (nrows < (1ll << 31) && (long long)g->H * g->W <= (1ll << 24)) {
         SpBuilder sb;
-        rc = sb.begin(&g->p2e_sp, (int)nrows);
+        rc = sb.begin(&g->p2e_sp, (int)nrows, stream);
         if (rc != OMNI_OK) return rc;
         hipLaunchKernelGGL(p2e_sp_walk_kernel, dim3(rows4 * g->ntx), dim3(256), 0, stream, a, (const float*)g->p2e_rden, sb.emit(0));
         OMNI_HIP(hipGetLastError());
         OMNI_HIP(hipStreamSynchronize(stream));
         bool fits = false;
-        rc = sb.layout((size_t)omni_options().bwd_table_mb << 20, &fits);
+        rc = sb.layout((size_t)omni_options().bwd_table_mb << 20, &fits, stream);
         if (rc != OMNI_OK) return rc;
         if (fits) {
             hipLaunchKernelGGL(p2e_sp_walk_kernel, dim3(rows4 * g->ntx), dim3(256), 0, stream, a, (const float*)g->p2e_rden, sb.emit(1));

@@ -280,16 +280,17 @@ __global__ __launch_bounds__(256) void sp_sort_kernel(uint2* ent, const int* __r
 struct SpBuilder {
     OmniSpTable* t; int* d_cnt = nullptr; int* d_rowpos = nullptr; std::vector<int> h_cnt;
     ~SpBuilder() { if (d_cnt) (void)hipFree(d_cnt); if (d_rowpos) (void)hipFree(d_rowpos); }
-    int begin(OmniSpTable* table, int nrows)
+    // (every memset below is issued ON the build's stream: a null-stream memset is not ordered against a non-blocking stream's kernels)
+    int begin(OmniSpTable* table, int nrows, hipStream_t stream)
     {
         t = table; t->nrows = nrows; t->nslices = (nrows + 63) / 64;
         OMNI_HIP(hipMalloc((void**)&d_cnt, sizeof(int) * (size_t)nrows));
-        OMNI_HIP(hipMemset(d_cnt, 0, sizeof(int) * (size_t)nrows));
+        OMNI_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)nrows, stream));
         return OMNI_OK;
     }
     SpEmit emit(int pass) const { SpEmit e; e.pass = pass; e.cnt = d_cnt; e.rowpos = d_rowpos; e.ent = t->ent; e.long_ent = t->long_ent; return e; }
     // after pass 0 (stream synchronised by the caller): returns OMNI_OK with t->ok == 0 when the table would exceed `budget`
-    int layout(size_t budget, bool* fits)
+    int layout(size_t budget, bool* fits, hipStream_t stream)
     {
         const int nrows = t->nrows, ns = t->nslices;
         h_cnt.resize(nrows);
@@ -314,7 +315,7 @@ struct SpBuilder {
         *fits = bytes <= budget;
         if (!*fits) return OMNI_OK;
         OMNI_HIP(hipMalloc((void**)&t->ent, sizeof(uint2) * (size_t)std::max<long long>(t->npadded, 1)));
-        OMNI_HIP(hipMemset(t->ent, 0, sizeof(uint2) * (size_t)std::max<long long>(t->npadded, 1)));
+        OMNI_HIP(hipMemsetAsync(t->ent, 0, sizeof(uint2) * (size_t)std::max<long long>(t->npadded, 1), stream));
         OMNI_HIP(hipMalloc((void**)&t->long_ent, sizeof(uint2) * (size_t)std::max<long long>(nl, 1)));
         OMNI_HIP(hipMalloc((void**)&t->slice_off, sizeof(int) * (size_t)(ns + 1)));
         OMNI_HIP(hipMalloc((void**)&t->cnt, sizeof(int) * (size_t)nrows));
@@ -326,7 +327,7 @@ struct SpBuilder {
         OMNI_HIP(hipMemcpy(t->long_off, loff.data(), sizeof(int) * loff.size(), hipMemcpyHostToDevice));
         if (!lrow.empty()) OMNI_HIP(hipMemcpy(t->long_row, lrow.data(), sizeof(int) * lrow.size(), hipMemcpyHostToDevice));
         OMNI_HIP(hipMemcpy(d_rowpos, rowpos.data(), sizeof(int) * (size_t)nrows, hipMemcpyHostToDevice));
-        OMNI_HIP(hipMemset(d_cnt, 0, sizeof(int) * (size_t)nrows));                // the cursors of pass 1
+        OMNI_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)nrows, stream));   // the cursors of pass 1
         h_loff.swap(loff);
         return OMNI_OK;
     }

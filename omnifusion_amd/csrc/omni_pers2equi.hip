@@ -1312,6 +1312,22 @@ __global__ __launch_bounds__(256) void p2e_bwd_box_kernel(P2EArgs a, int* __rest
     if (inside) rden[(size_t)i * a.W + j] = 1.0f / fmaxf(l1, 1e-12f);
 }
 
+// planar [planes][N][pp] -> the reference's [planes][pp][N] (N innermost), 64 samples of all N patches per block through LDS: coalesced
+// reads (N runs of 256 bytes) and one contiguous run of 64 N floats out.  (Writing N-innermost straight from the gather kernel puts 4 bytes
+// into every 4 N: 260 MB of write traffic for 38 MB at 18 x 256^2.)
+__global__ __launch_bounds__(256) void p2e_nlast_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int pp, int C)
+{
+    extern __shared__ float nl_tile[];                            // [64][N | 1]
+    const int NP = N | 1, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int p = blockIdx.y, b = p / C, c = p - b * C, s0 = blockIdx.x * 64, ns = min(64, pp - s0);
+    const float* sp = src + ((size_t)b * N * C + c) * pp + s0;    // + n * C * pp
+    for (int n = wave; n < N; n += 4)
+        if (lane < ns) nl_tile[lane * NP + n] = sp[(size_t)n * C * pp + lane];
+    __syncthreads();
+    float* dp = dst + ((size_t)p * pp + s0) * N;
+    for (int i = t; i < ns * N; i += 256) { const int px = i / N, n = i - px * N; dp[i] = nl_tile[px * NP + n]; }
+}
+
 // The transpose as a sparse matrix (omni_spgather.h): every (ERP pixel, covering patch, tap with a non-zero weight) is one entry
 // (source = the pixel, weight = w_tap / l1) of the row of the patch pixel the tap reads.  Same traversal and tap function as above.
 __global__ __launch_bounds__(256) void p2e_sp_walk_kernel(P2EArgs a, const float* __restrict__ rden, SpEmit b)
@@ -1498,8 +1514,20 @@ extern "C" int omni_pers2equi_bwd(const void* grad_erp, void* grad_pers, int dty
         s.PT = (B * C + 3) / 4 * 4; s.nhi = 1; s.nlo = H * W; s.hi_fastest = 0; s.chunk = 16;
         float* ws = nullptr;
         if (omni_options().bwd_wide) {
-            rc = omni_bwd_workspace(const_cast<omni_geometry*>(g), (hipStream_t)stream, (size_t)H * W * s.PT * sizeof(float), &ws);
+            // reference layout: the gathers write the planar form into the scratch, p2e_nlast_kernel turns it N-innermost
+            const size_t n1 = (size_t)H * W * s.PT, n2 = layout == OMNI_LAYOUT_BCHWN ? (size_t)B * C * g->N * ph * pw : 0;
+            rc = omni_bwd_workspace(const_cast<omni_geometry*>(g), (hipStream_t)stream, (n1 + n2) * sizeof(float), &ws);
             if (rc != OMNI_OK) return rc;
+            if (n2) {
+                const long long pp = (long long)ph * pw;
+                s.dst = ws + n1; s.d_sB = (long long)g->N * C * pp; s.d_sC = pp; s.d_hi = C * pp; s.d_lo = 1;
+                rc = sp_apply(g->p2e_sp, s, (hipStream_t)stream, ws);
+                if (rc != OMNI_OK) return rc;
+                hipLaunchKernelGGL(p2e_nlast_kernel, dim3((unsigned)((pp + 63) / 64), (unsigned)(B * C)), dim3(256), sizeof(float) * 64 * (g->N | 1), (hipStream_t)stream,
+                                   (const float*)(ws + n1), (float*)grad_pers, g->N, (int)pp, C);
+                OMNI_HIP(hipGetLastError());
+                return OMNI_OK;
+            }
         }
         return sp_apply(g->p2e_sp, s, (hipStream_t)stream, ws);
     }

@@ -210,3 +210,35 @@ def test_backward_under_capture_keeps_its_scratch():
     torch.cuda.synchronize()
     assert torch.equal(t2[2], want[0]) and torch.equal(t2[3], want[1])
     lib.omni_geometry_cache_clear()
+
+
+def test_backward_every_plane_count():
+    """the gather kernels are instantiated per plane-group size (4 / 8 / 12 / 16 / 24 planes per pass, the gradient's planes padded to a multiple
+    of 4): every B * C from 1 to 26, both layouts, against the plain scatter kernels; the 16-byte and the 4-byte forms agree bit for bit"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    nrows, P, H, W, N = 4, 16, 40, 80, 18
+    f80 = ctypes.c_float(80)
+    try:
+        for planes in range(1, 27):
+            B, C = (planes // 3, 3) if planes % 3 == 0 else (planes, 1)
+            for layout in (L.LAYOUT_BNCHW, L.LAYOUT_BCHWN):
+                gp = torch.rand((B, N, C, P, P) if layout == L.LAYOUT_BNCHW else (B, C, P, P, N), device=DEV)
+                ge = torch.rand((B, C, H, W), device=DEV)
+                res = []
+                for wide, e2p_mode, p2e_mode in ((1, 0, 0), (0, 0, 0), (1, 1, 1)):
+                    L.set_option("bwd_wide", wide); L.set_option("e2p_bwd_simple", e2p_mode); L.set_option("p2e_bwd_simple", p2e_mode)
+                    oe = torch.full((B, C, H, W), float("nan"), device=DEV); op = torch.full_like(gp, float("nan"))
+                    assert lib.omni_equi2pers_bwd(P_(gp), P_(oe), 0, B, C, H, W, P, P, nrows, f80, f80, layout, None) == 0, lib.omni_last_error()
+                    assert lib.omni_pers2equi_bwd(P_(ge), P_(op), 0, B, C, P, P, H, W, nrows, f80, f80, layout, None) == 0, lib.omni_last_error()
+                    res.append((oe, op))
+                torch.cuda.synchronize()
+                assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (planes, layout)
+                for k in (0, 1):
+                    assert bool(torch.isfinite(res[0][k]).all())
+                    d = (res[0][k] - res[2][k]).abs().max().item()
+                    assert d <= 2e-5 * max(1.0, res[2][k].abs().max().item()), (planes, layout, k, d)
+    finally:
+        L.set_option("bwd_wide", 1); L.set_option("e2p_bwd_simple", 0); L.set_option("p2e_bwd_simple", 0)

@@ -41,6 +41,7 @@ const OptName kOpts[] = {
     {"p2e_bwd_simple", "OMNI_P2E_BWD_SIMPLE", &OmniOptions::p2e_bwd_simple, 0},
     {"bwd_table_mb", "OMNI_BWD_TABLE_MB", &OmniOptions::bwd_table_mb, 1024},
     {"bwd_wide", "OMNI_BWD_WIDE", &OmniOptions::bwd_wide, 1},
+    {"bwd_lmax", "OMNI_BWD_LMAX", &OmniOptions::bwd_lmax, 0},
     {"bwd_chunk", "OMNI_BWD_CHUNK", &OmniOptions::bwd_chunk, 0},
     {"p2e_gather", "OMNI_P2E_GATHER", &OmniOptions::p2e_gather, 0},
     {"e2p_nbuf", "OMNI_E2P_NBUF", &OmniOptions::e2p_nbuf, 0},

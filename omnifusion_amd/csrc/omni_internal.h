@@ -60,6 +60,7 @@ struct OmniOptions {
     int p2e_walk;         // OMNI_P2E_WALK       1 (default): the flat-pipeline kernel p2e_walk_kernel (one stage stream per tile across its patches, stages consumed in pairs) | 0: p2e_lds_kernel (patch by patch)
     int bwd_wide;         // OMNI_BWD_WIDE       1 (default): the backward gathers read a plane-interleaved copy of the gradient (16-byte gathers) | 0: the gradient itself (4-byte gathers, no scratch)
     int bwd_chunk;        // OMNI_BWD_CHUNK      blocks per XCD chunk of the backward gathers (0: 16; 4 .. 64 measured within 3 %)
+    int bwd_lmax;         // OMNI_BWD_LMAX       rows with more entries than this go to the long-row list (0: OMNI_SP_LMAX; read when a table is built)
     int bwd_table_mb;     // OMNI_BWD_TABLE_MB   largest sparse-matrix table of a backward operator kept per geometry, MiB (default 1024; a geometry past it keeps the tile kernels)
     int geom_cache_max;   // OMNI_GEOM_CACHE_MAX geometry handles kept per process (LRU), default 16
 };
@@ -93,7 +94,7 @@ struct PatchTab {
 // holds K_s = slice_off[s+1] - slice_off[s] entries per row, entry k of row r at ent[(slice_off[s] * 64) + k * 64 + (r & 63)]; cnt[r] of them are
 // real.  Rows with more than OMNI_SP_LMAX entries (patch pixels at a pole: a whole ERP row maps onto them) live in a CSR side list instead
 // (cnt[r] = -1) and get a block each.  Entries of a row are sorted by source index: the summation order is a constant of the geometry.
-constexpr int OMNI_SP_LMAX = 24;
+constexpr int OMNI_SP_LMAX = 48;   // (24 .. 64 measured: equi2pers^T has no row past 48 and gains 12 % from keeping them all in the slices; pers2equi^T is flat)
 struct OmniSpTable {
     uint2* ent = nullptr; int* slice_off = nullptr; int* cnt = nullptr;
     uint2* long_ent = nullptr; int* long_off = nullptr; int* long_row = nullptr;

@@ -22,7 +22,7 @@ namespace {
 // how one application addresses its operands: source element of entry e (hi 8 bits | lo 24 bits of e.x) and plane p, destination of row r
 struct SpApply {
     const uint2* ent; const int* slice_off; const int* cnt; int nrows, nslices;
-    const uint2* long_ent; const int* long_off; const int* long_row;
+    const uint2* long_ent; const int* long_off; const int* long_row; int nlong;
     const float* src; float* dst;
     int C, planes;                        // plane p = (batch p / C, channel p % C)
     long long s_sB, s_sC, d_sB, d_sC;     // element strides of batch / channel in source and destination
@@ -33,8 +33,8 @@ struct SpApply {
     const float* ws; int PT; int nhi, nlo, hi_fastest;   // record index = hi_fastest ? lo * nhi + hi : hi * nlo + lo  (the order the source itself is contiguous in)
 };
 
-// One wave per slice of 64 rows, PL planes in registers; the blocks past the slices take one long row each (fixed partition of its entries
-// over the 256 threads and a fixed reduction tree: deterministic).  A slice's entries are consumed four at a time: the four table loads,
+// One wave per slice of 64 rows, PL planes in registers; the blocks past the slices take four long rows each, one per wave (fixed
+// partition of a row's entries over the 64 lanes and a fixed shuffle tree: deterministic).  A slice's entries are consumed four at a time: the four table loads,
 // then their 4 x PL gathers, are all in flight together (a chain of dependent round trips otherwise: 110 -> 60 us for pers2equi^T);
 // a padding slot gathers element 0 and contributes nothing (its VALUE is masked, not its weight: a non-finite gradient at element 0 stays where it is).
 template <int PL>
@@ -51,30 +51,24 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_bl
 #pragma unroll
     for (int p = 0; p < PL; ++p) acc[p] = 0.0f;
 
-    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- a long row
-        __shared__ float part[4][PL];
-        const int lr = blockIdx.x - nslice_blocks, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- long rows: one per wave, entries strided over its lanes, fixed shuffle tree
+        const int lr = (blockIdx.x - nslice_blocks) * 4 + (threadIdx.x >> 6);
+        if (lr >= s.nlong) return;
         const int row = s.long_row[lr], o0 = s.long_off[lr], o1 = s.long_off[lr + 1];
-        for (int i = o0 + (int)threadIdx.x; i < o1; i += 256) {
+        for (int i = o0 + lane; i < o1; i += 64) {
             const uint2 en = s.long_ent[i];
             const int off = (int)(en.x >> 24) * s.s_hi + (int)(en.x & 0xffffffu) * s.s_lo;
             const float w = __uint_as_float(en.y);
 #pragma unroll
             for (int p = 0; p < PL; ++p) acc[p] = fmaf(sp[p][off], w, acc[p]);
         }
+        const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
             float v = acc[p];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0) part[wave][p] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < PL && p0 + (int)threadIdx.x < s.planes) {
-            const int p = threadIdx.x;
-            const float v = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
-            const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
-            s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
+            if (lane == 0 && p0 + p < s.planes) s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
         }
         return;
     }
@@ -167,11 +161,11 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
         return reinterpret_cast<const float4*>(wsp + (size_t)((int)(src >> 24) * r_hi + (int)(src & 0xffffffu) * r_lo) * s.PT);
     };
 
-    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- a long row
-        __shared__ float part[4][PG];
-        const int lr = blockIdx.x - nslice_blocks, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- long rows: one per wave
+        const int lr = (blockIdx.x - nslice_blocks) * 4 + (threadIdx.x >> 6);
+        if (lr >= s.nlong) return;
         const int row = s.long_row[lr], o0 = s.long_off[lr], o1 = s.long_off[lr + 1];
-        for (int i = o0 + (int)threadIdx.x; i < o1; i += 256) {
+        for (int i = o0 + lane; i < o1; i += 64) {
             const uint2 en = s.long_ent[i];
             const float4* rp = rec_ptr(en.x);
             const float w = __uint_as_float(en.y);
@@ -182,19 +176,13 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
                 acc[4 * q + 2] = fmaf(v.z, w, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v.w, w, acc[4 * q + 3]);
             }
         }
+        const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
 #pragma unroll
         for (int p = 0; p < PG; ++p) {
             float v = acc[p];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0) part[wave][p] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < PG && p0 + (int)threadIdx.x < s.planes) {
-            const int p = threadIdx.x;
-            const float v = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
-            const size_t doff = (size_t)(row / s.rdiv) * s.d_hi + (size_t)(row % s.rdiv) * s.d_lo;
-            s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
+            if (lane == 0 && p0 + p < s.planes) s.dst[(size_t)((p0 + p) / s.C) * s.d_sB + (size_t)((p0 + p) % s.C) * s.d_sC + doff] = v;
         }
         return;
     }
@@ -267,7 +255,7 @@ __global__ __launch_bounds__(256) void sp_sort_kernel(uint2* ent, const int* __r
     if (row >= nrows) return;
     const int n = cnt[row];
     uint2* e = ent + (size_t)slice_off[row >> 6] * 64 + (row & 63);
-    for (int i = 1; i < n; ++i) {                                  // insertion sort, n <= OMNI_SP_LMAX
+    for (int i = 1; i < n; ++i) {                                  // insertion sort, n <= the long-row threshold
         const uint2 key = e[(size_t)i * 64];
         int j = i - 1;
         while (j >= 0 && sp_after(e[(size_t)j * 64], key)) { e[(size_t)(j + 1) * 64] = e[(size_t)j * 64]; --j; }
@@ -293,22 +281,30 @@ struct SpBuilder {
     int layout(size_t budget, bool* fits, hipStream_t stream)
     {
         const int nrows = t->nrows, ns = t->nslices;
+        const int lmax = omni_options().bwd_lmax > 0 ? omni_options().bwd_lmax : OMNI_SP_LMAX;
         h_cnt.resize(nrows);
         OMNI_HIP(hipMemcpy(h_cnt.data(), d_cnt, sizeof(int) * (size_t)nrows, hipMemcpyDeviceToHost));
         std::vector<int> so(ns + 1, 0), rowpos(nrows), lrow, loff(1, 0), tcnt(nrows);
         long long nent = 0, nl = 0;
         for (int s = 0; s < ns; ++s) {
             int K = 0;
-            for (int r = s * 64; r < std::min(nrows, s * 64 + 64); ++r) if (h_cnt[r] <= OMNI_SP_LMAX) K = std::max(K, h_cnt[r]);
+            for (int r = s * 64; r < std::min(nrows, s * 64 + 64); ++r) if (h_cnt[r] <= lmax) K = std::max(K, h_cnt[r]);
             so[s + 1] = so[s] + K;
             if ((long long)so[s + 1] * 64 >= (1ll << 31)) { *fits = false; return OMNI_OK; }
         }
         for (int r = 0; r < nrows; ++r) {
-            if (h_cnt[r] <= OMNI_SP_LMAX) { rowpos[r] = so[r >> 6] * 64 + (r & 63); tcnt[r] = h_cnt[r]; nent += h_cnt[r]; }
+            if (h_cnt[r] <= lmax) { rowpos[r] = so[r >> 6] * 64 + (r & 63); tcnt[r] = h_cnt[r]; nent += h_cnt[r]; }
             else {
                 if (nl + h_cnt[r] >= (1ll << 31) - 1) { *fits = false; return OMNI_OK; }
                 rowpos[r] = -1 - (int)nl; tcnt[r] = -1; lrow.push_back(r); nl += h_cnt[r]; loff.push_back((int)nl);
             }
+        }
+        if (omni_options().e2p_verbose) {
+            long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // rows by entry count: <= 4, 8, 16, 24, 32, 48, 64, more
+            const int edge[7] = {4, 8, 16, 24, 32, 48, 64};
+            for (int r = 0; r < nrows; ++r) { int b = 0; while (b < 7 && h_cnt[r] > edge[b]) ++b; ++hist[b]; }
+            fprintf(stderr, "[omni] sparse rows by entry count (<=4 <=8 <=16 <=24 <=32 <=48 <=64 more): %lld %lld %lld %lld %lld %lld %lld %lld\n",
+                    hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
         }
         t->nent = nent; t->npadded = (long long)so[ns] * 64; t->nlong = (int)lrow.size(); t->nlong_ent = nl;
         const size_t bytes = (size_t)(t->npadded + nl) * sizeof(uint2) + (size_t)nrows * 4;
@@ -355,26 +351,26 @@ struct SpBuilder {
 inline int sp_apply(const OmniSpTable& t, SpApply s, hipStream_t stream, float* ws)
 {
     s.ent = t.ent; s.slice_off = t.slice_off; s.cnt = t.cnt; s.nrows = t.nrows; s.nslices = t.nslices;
-    s.long_ent = t.long_ent; s.long_off = t.long_off; s.long_row = t.long_row;
+    s.long_ent = t.long_ent; s.long_off = t.long_off; s.long_row = t.long_row; s.nlong = t.nlong;
     const int nb = (t.nslices + 3) / 4;
     if (omni_options().bwd_chunk > 0) s.chunk = omni_options().bwd_chunk;
     if (ws) {
         const int R = s.nhi * s.nlo;
         s.ws = ws;
         hipLaunchKernelGGL(sp_interleave_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)((s.PT + SP_ICH - 1) / SP_ICH)), dim3(256), 0, stream, s, ws, R);
-        if (s.PT % 24 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<24>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 24)), dim3(256), 0, stream, s, nb);
-        else if (s.PT % 16 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<16>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 16)), dim3(256), 0, stream, s, nb);
-        else if (s.PT % 12 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nb);
-        else if (s.PT % 8 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<8>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 8)), dim3(256), 0, stream, s, nb);
-        else                    hipLaunchKernelGGL(sp_gather_wide_kernel<4>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.PT / 4)), dim3(256), 0, stream, s, nb);
+        if (s.PT % 24 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<24>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 24)), dim3(256), 0, stream, s, nb);
+        else if (s.PT % 16 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<16>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 16)), dim3(256), 0, stream, s, nb);
+        else if (s.PT % 12 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nb);
+        else if (s.PT % 8 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<8>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 8)), dim3(256), 0, stream, s, nb);
+        else                    hipLaunchKernelGGL(sp_gather_wide_kernel<4>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 4)), dim3(256), 0, stream, s, nb);
         OMNI_HIP(hipGetLastError());
         return OMNI_OK;
     }
     s.ws = nullptr;
     if (s.planes > 8 && s.planes % 12 == 0)
-        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3((unsigned)(nb + t.nlong), (unsigned)(s.planes / 12)), dim3(256), 0, stream, s, nb);
+        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.planes / 12)), dim3(256), 0, stream, s, nb);
     else
-        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3((unsigned)(nb + t.nlong), (unsigned)((s.planes + 7) / 8)), dim3(256), 0, stream, s, nb);
+        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)((s.planes + 7) / 8)), dim3(256), 0, stream, s, nb);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

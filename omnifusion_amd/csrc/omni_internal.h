@@ -93,7 +93,7 @@ struct PatchTab {
 // A linear operator of the geometry as a sparse matrix in sliced-ELL form (omni_spgather.h): rows in slices of 64 (one per lane of a wave), slice s
 // holds K_s = slice_off[s+1] - slice_off[s] entries per row, entry k of row r at ent[(slice_off[s] * 64) + k * 64 + (r & 63)]; cnt[r] of them are
 // real.  Rows with more than OMNI_SP_LMAX entries (patch pixels at a pole: a whole ERP row maps onto them) live in a CSR side list instead
-// (cnt[r] = -1) and get a block each.  Entries of a row are sorted by source index: the summation order is a constant of the geometry.
+// (cnt[r] = -1) and get a wave each.  Entries of a row are sorted by source index: the summation order is a constant of the geometry.
 constexpr int OMNI_SP_LMAX = 48;   // (24 .. 64 measured: equi2pers^T has no row past 48 and gains 12 % from keeping them all in the slices; pers2equi^T is flat)
 struct OmniSpTable {
     uint2* ent = nullptr; int* slice_off = nullptr; int* cnt = nullptr;

@@ -26,7 +26,7 @@ for f in glob.glob(f"{out}/p*/**/*kernel_trace.csv", recursive=True):
         dur[(r["Kernel_Name"], str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("# tools/pmc_bwd.sh: operator backwards at B = 8, 512x1024, 18 x 256^2 (equi2pers C = 3, pers2equi C = 1); means per launch; fetch = FETCH_SIZE x 2 KiB (gfx950), write = WRITE_SIZE KiB")
 for k in sorted(agg, key=lambda n: -sum(dur[n])):
-    if len(dur[k]) < 10: continue
+    if len(dur[k]) < 10 or not any(t in k[0] for t in ("sp_gather", "sp_interleave", "p2e_nlast", "bwd")): continue
     m = {c: sum(v) / len(v) for c, v in agg[k].items()}
     nm = re.sub(r"\(anonymous namespace\)::|void ", "", k[0]).split("(")[0]
     print(f"== {nm} grid {k[1]}: {sum(dur[k]) / len(dur[k]):.1f} us under the counters, {len(dur[k])} launches")

@@ -6,7 +6,7 @@
 //                 (what autograd derives from the advanced-indexing gathers of pers2equi_v3.py:174-196)
 //   equi2pers^T:  g_erp[i, j]      = sum over the patch samples whose taps touch (i, j) of w_tap * g_pers[n, h, w]
 //                 (ATen grid_sampler_2d_backward, bilinear / border / align_corners=True, equi2pers_v3.py:111)
-// ~4 and ~9 entries per output element.  The kernels of rounds 2-3 re-derived the taps on every call and reduced them through LDS or global
+// ~3.5 and ~9 entries per output element.  The kernels of rounds 2-3 re-derived the taps on every call and reduced them through LDS or global
 // atomics (0.32 / 0.74 ms at B = 8, 512 x 1024, 18 x 256^2: 0.17 / 0.22 TB/s); here a call is one pass over the 8-byte entries (coalesced: the
 // sliced-ELL layout puts entry k of 64 consecutive rows side by side), one gather per entry and plane from a source that sits in L2, one
 // coalesced store per output element — no atomics anywhere, and the summation order is a constant of the geometry (entries sorted by source).
@@ -33,12 +33,15 @@ struct SpApply {
     const float* ws; int PT; int nhi, nlo, hi_fastest;   // record index = hi_fastest ? lo * nhi + hi : hi * nlo + lo  (the order the source itself is contiguous in)
 };
 
-// One wave per slice of 64 rows, PL planes in registers; the blocks past the slices take four long rows each, one per wave (fixed
+// One wave per slice of 64 rows, PL planes in registers; the first blocks of the grid take four long rows each (longest first), one per wave (fixed
 // partition of a row's entries over the 64 lanes and a fixed shuffle tree: deterministic).  A slice's entries are consumed four at a time: the four table loads,
-// then their 4 x PL gathers, are all in flight together (a chain of dependent round trips otherwise: 110 -> 60 us for pers2equi^T);
-// a padding slot gathers element 0 and contributes nothing (its VALUE is masked, not its weight: a non-finite gradient at element 0 stays where it is).
+// then their 4 x PL gathers, are all in flight together (a chain of dependent round trips otherwise: 133 -> 111 us for pers2equi^T);
+// a padding slot gathers element 0 (one hot line) and contributes nothing: its VALUE is masked, not its weight, so a non-finite gradient at
+// element 0 stays where it is (test_backward_keeps_non_finite_gradients_local).  Measured alternatives: the masked lanes sitting the entry out
+// (a branch per entry: the loads serialise, 127 -> 177 us); padding that repeats the row's own first source with weight 0, nothing to mask
+// (127 -> 147 us: four in ten slots are padding and then fetch real, scattered lines).
 template <int PL>
-__global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_blocks)
+__global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nlong_blocks, int nslice_blocks)
 {
     const int lane = threadIdx.x & 63, p0 = blockIdx.y * PL;
     const float* sp[PL];
@@ -51,10 +54,11 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_bl
 #pragma unroll
     for (int p = 0; p < PL; ++p) acc[p] = 0.0f;
 
-    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- long rows: one per wave, entries strided over its lanes, fixed shuffle tree
-        const int lr = (blockIdx.x - nslice_blocks) * 4 + (threadIdx.x >> 6);
+    if ((int)blockIdx.x < nlong_blocks) {                          // ---- long rows (first in the grid, longest first): one per wave, entries strided over its lanes, fixed shuffle tree
+        const int lr = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (lr >= s.nlong) return;
         const int row = s.long_row[lr], o0 = s.long_off[lr], o1 = s.long_off[lr + 1];
+#pragma unroll 4
         for (int i = o0 + lane; i < o1; i += 64) {
             const uint2 en = s.long_ent[i];
             const int off = (int)(en.x >> 24) * s.s_hi + (int)(en.x & 0xffffffu) * s.s_lo;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(SpApply s, int nslice_bl
 
     // (hardware block b runs on XCD b % 8: every XCD gets one contiguous range of slices, so neighbouring rows — which gather the same
     //  source lines — share one L2; in chunks of s.chunk blocks dealt round-robin, because the rows near a pole are the expensive ones)
-    unsigned lb = blockIdx.x;
+    unsigned lb = blockIdx.x - nlong_blocks;                      // (nlong_blocks is a multiple of 8: logical block lb still runs on XCD lb % 8)
     {
         const unsigned ch = (unsigned)s.chunk, span = 8u * ch, full = (unsigned)nslice_blocks / span * span;
         if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / ch) * 8u + x) * ch + q % ch; }
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void sp_interleave_kernel(SpApply s, float* __
 }
 
 template <int PG>                                                  // planes per pass (a multiple of 4)
-__global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nslice_blocks)
+__global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nlong_blocks, int nslice_blocks)
 {
     constexpr int Q = PG / 4;
     const int lane = threadIdx.x & 63, p0 = blockIdx.y * PG;
@@ -161,10 +165,11 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
         return reinterpret_cast<const float4*>(wsp + (size_t)((int)(src >> 24) * r_hi + (int)(src & 0xffffffu) * r_lo) * s.PT);
     };
 
-    if ((int)blockIdx.x >= nslice_blocks) {                        // ---- long rows: one per wave
-        const int lr = (blockIdx.x - nslice_blocks) * 4 + (threadIdx.x >> 6);
+    if ((int)blockIdx.x < nlong_blocks) {                          // ---- long rows: one per wave
+        const int lr = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (lr >= s.nlong) return;
         const int row = s.long_row[lr], o0 = s.long_off[lr], o1 = s.long_off[lr + 1];
+#pragma unroll 4
         for (int i = o0 + lane; i < o1; i += 64) {
             const uint2 en = s.long_ent[i];
             const float4* rp = rec_ptr(en.x);
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
         return;
     }
 
-    unsigned lb = blockIdx.x;                                      // (XCD map as in sp_gather_kernel)
+    unsigned lb = blockIdx.x - nlong_blocks;                      // (XCD map as in sp_gather_kernel)
     {
         const unsigned ch = (unsigned)s.chunk, span = 8u * ch, full = (unsigned)nslice_blocks / span * span;
         if (lb < full) { const unsigned x = lb & 7u, q = lb >> 3; lb = ((q / ch) * 8u + x) * ch + q % ch; }
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void sp_gather_wide_kernel(SpApply s, int nsli
     const int o0 = s.slice_off[slice], K = s.slice_off[slice + 1] - o0;
     const int nk = row < s.nrows ? s.cnt[row] : -1;
     const uint2* e = s.ent + (size_t)o0 * 64 + lane;
-    constexpr int U = PG >= 16 ? 2 : 4;
+    constexpr int U = PG >= 16 ? 2 : 4;                          // entries in flight together (registers: U * PG / 4 float4; 8 for PG = 8 measured: no change)
     for (int k0 = 0; k0 < K; k0 += U) {
         uint2 en[U];
 #pragma unroll
@@ -306,6 +311,18 @@ struct SpBuilder {
             fprintf(stderr, "[omni] sparse rows by entry count (<=4 <=8 <=16 <=24 <=32 <=48 <=64 more): %lld %lld %lld %lld %lld %lld %lld %lld\n",
                     hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
         }
+        if (!lrow.empty()) {                                       // longest first (they start first: the launch ends with the slices, not with one wave's 2000 entries)
+            std::vector<int> order(lrow.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_cnt[lrow[a]] > h_cnt[lrow[b]]; });
+            std::vector<int> lrow2(lrow.size()), loff2(1, 0);
+            long long pos = 0;
+            for (size_t i = 0; i < order.size(); ++i) {
+                const int r = lrow[order[i]];
+                lrow2[i] = r; rowpos[r] = -1 - (int)pos; pos += h_cnt[r]; loff2.push_back((int)pos);
+            }
+            lrow.swap(lrow2); loff.swap(loff2);
+        }
         t->nent = nent; t->npadded = (long long)so[ns] * 64; t->nlong = (int)lrow.size(); t->nlong_ent = nl;
         const size_t bytes = (size_t)(t->npadded + nl) * sizeof(uint2) + (size_t)nrows * 4;
         *fits = bytes <= budget;
@@ -352,25 +369,25 @@ inline int sp_apply(const OmniSpTable& t, SpApply s, hipStream_t stream, float* 
 {
     s.ent = t.ent; s.slice_off = t.slice_off; s.cnt = t.cnt; s.nrows = t.nrows; s.nslices = t.nslices;
     s.long_ent = t.long_ent; s.long_off = t.long_off; s.long_row = t.long_row; s.nlong = t.nlong;
-    const int nb = (t.nslices + 3) / 4;
+    const int nb = (t.nslices + 3) / 4, nlb = ((t.nlong + 3) / 4 + 7) / 8 * 8;
     if (omni_options().bwd_chunk > 0) s.chunk = omni_options().bwd_chunk;
     if (ws) {
         const int R = s.nhi * s.nlo;
         s.ws = ws;
         hipLaunchKernelGGL(sp_interleave_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)((s.PT + SP_ICH - 1) / SP_ICH)), dim3(256), 0, stream, s, ws, R);
-        if (s.PT % 24 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<24>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 24)), dim3(256), 0, stream, s, nb);
-        else if (s.PT % 16 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<16>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 16)), dim3(256), 0, stream, s, nb);
-        else if (s.PT % 12 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nb);
-        else if (s.PT % 8 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<8>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 8)), dim3(256), 0, stream, s, nb);
-        else                    hipLaunchKernelGGL(sp_gather_wide_kernel<4>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.PT / 4)), dim3(256), 0, stream, s, nb);
+        if (s.PT % 24 == 0)     hipLaunchKernelGGL(sp_gather_wide_kernel<24>, dim3((unsigned)(nb + nlb), (unsigned)(s.PT / 24)), dim3(256), 0, stream, s, nlb, nb);
+        else if (s.PT % 16 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<16>, dim3((unsigned)(nb + nlb), (unsigned)(s.PT / 16)), dim3(256), 0, stream, s, nlb, nb);
+        else if (s.PT % 12 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<12>, dim3((unsigned)(nb + nlb), (unsigned)(s.PT / 12)), dim3(256), 0, stream, s, nlb, nb);
+        else if (s.PT % 8 == 0) hipLaunchKernelGGL(sp_gather_wide_kernel<8>, dim3((unsigned)(nb + nlb), (unsigned)(s.PT / 8)), dim3(256), 0, stream, s, nlb, nb);
+        else                    hipLaunchKernelGGL(sp_gather_wide_kernel<4>, dim3((unsigned)(nb + nlb), (unsigned)(s.PT / 4)), dim3(256), 0, stream, s, nlb, nb);
         OMNI_HIP(hipGetLastError());
         return OMNI_OK;
     }
     s.ws = nullptr;
     if (s.planes > 8 && s.planes % 12 == 0)
-        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)(s.planes / 12)), dim3(256), 0, stream, s, nb);
+        hipLaunchKernelGGL(sp_gather_kernel<12>, dim3((unsigned)(nb + nlb), (unsigned)(s.planes / 12)), dim3(256), 0, stream, s, nlb, nb);
     else
-        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3((unsigned)(nb + (t.nlong + 3) / 4), (unsigned)((s.planes + 7) / 8)), dim3(256), 0, stream, s, nb);
+        hipLaunchKernelGGL(sp_gather_kernel<8>, dim3((unsigned)(nb + nlb), (unsigned)((s.planes + 7) / 8)), dim3(256), 0, stream, s, nlb, nb);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

@@ -242,3 +242,33 @@ def test_backward_every_plane_count():
                     assert d <= 2e-5 * max(1.0, res[2][k].abs().max().item()), (planes, layout, k, d)
     finally:
         L.set_option("bwd_wide", 1); L.set_option("e2p_bwd_simple", 0); L.set_option("p2e_bwd_simple", 0)
+
+
+def test_backward_keeps_non_finite_gradients_local():
+    """a NaN / Inf in the incoming gradient reaches exactly the outputs whose entries read it: the padding slots of the sparse tables (which
+    read element 0) and the rows without entries must not spread it — compared with the plain scatter kernels"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    B, C, nrows, P, H, W, N = 1, 1, 4, 32, 64, 128, 18
+    f80 = ctypes.c_float(80)
+    gp = torch.rand((B, N, C, P, P), device=DEV); ge = torch.rand((B, C, H, W), device=DEV)
+    gp.view(-1)[0] = float("nan"); gp[0, 3, 0, 10, 11] = float("inf")       # element 0 is what an empty slot would read
+    ge.view(-1)[0] = float("nan"); ge[0, 0, 30, 40] = float("inf")
+    res = []
+    try:
+        for e2p_mode, p2e_mode, wide in ((0, 0, 1), (0, 0, 0), (1, 1, 1)):
+            L.set_option("e2p_bwd_simple", e2p_mode); L.set_option("p2e_bwd_simple", p2e_mode); L.set_option("bwd_wide", wide)
+            oe = torch.zeros((B, C, H, W), device=DEV); op = torch.zeros_like(gp)
+            assert lib.omni_equi2pers_bwd(P_(gp), P_(oe), 0, B, C, H, W, P, P, nrows, f80, f80, L.LAYOUT_BNCHW, None) == 0
+            assert lib.omni_pers2equi_bwd(P_(ge), P_(op), 0, B, C, P, P, H, W, nrows, f80, f80, L.LAYOUT_BNCHW, None) == 0
+            res.append((oe, op))
+    finally:
+        L.set_option("e2p_bwd_simple", 0); L.set_option("p2e_bwd_simple", 0); L.set_option("bwd_wide", 1)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        want = ~torch.isfinite(res[2][k])
+        assert 0 < int(want.sum()) < want.numel() // 4
+        for j in (0, 1):
+            assert torch.equal(~torch.isfinite(res[j][k]), want), (k, j, int((~torch.isfinite(res[j][k])).sum()), int(want.sum()))

@@ -272,3 +272,58 @@ def test_backward_keeps_non_finite_gradients_local():
         assert 0 < int(want.sum()) < want.numel() // 4
         for j in (0, 1):
             assert torch.equal(~torch.isfinite(res[j][k]), want), (k, j, int((~torch.isfinite(res[j][k])).sum()), int(want.sum()))
+
+
+def test_adjoint_identity_random_geometries():
+    """<J x, y> == <x, J^T y> for both operators on a dozen random geometries (odd sizes, every nrows preset, rectangular patches, ERP sizes that
+    are no multiple of a slice): a size-independent property of the transposes as they are tabulated"""
+    equi2pers, equi2pers_patches, pers2equi, L = _ops()
+    rs = np.random.RandomState(7)
+    for _ in range(12):
+        nrows = int(rs.choice([3, 4, 5, 6]))
+        N = {3: 10, 4: 18, 5: 26, 6: 46}[nrows]
+        ph, pw = int(rs.randint(5, 41)), int(rs.randint(5, 41))
+        H = int(rs.randint(24, 97)); W = int(rs.randint(2 * H - 10, 2 * H + 11))
+        B, C = int(rs.randint(1, 4)), int(rs.randint(1, 4))
+        layout = L.LAYOUT_BNCHW if rs.rand() < 0.5 else L.LAYOUT_BCHWN
+        x = torch.rand((B, C, H, W), device=DEV, requires_grad=True)
+        fwd = equi2pers_patches(x, (80, 80), nrows, (ph, pw), layout=layout)
+        y = torch.rand_like(fwd)
+        (fwd * y).sum().backward()
+        lhs = float((fwd.detach().double() * y.double()).sum()); rhs = float((x.detach().double() * x.grad.double()).sum())
+        assert abs(lhs - rhs) <= 5e-5 * abs(lhs), ("e2p", nrows, ph, pw, H, W, B, C, layout, lhs, rhs)
+        shape = (B, C, ph, pw, N) if layout == L.LAYOUT_BCHWN else (B, N, C, ph, pw)
+        p = torch.rand(shape, device=DEV, requires_grad=True)
+        e = pers2equi(p, (80, 80), nrows, (ph, pw), (H, W), None, layout=layout)
+        z = torch.rand_like(e)
+        (e * z).sum().backward()
+        lhs = float((e.detach().double() * z.double()).sum()); rhs = float((p.detach().double() * p.grad.double()).sum())
+        assert abs(lhs - rhs) <= 5e-5 * abs(lhs), ("p2e", nrows, ph, pw, H, W, B, C, layout, lhs, rhs)
+
+
+def test_backward_without_tables_falls_back():
+    """a geometry whose sparse tables would exceed OMNI_BWD_TABLE_MB keeps the tile kernels of rounds 2-3: same results"""
+    _, _, _, L = _ops()
+    import ctypes
+    lib = L.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    B, C, nrows, P, H, W, N = 2, 2, 4, 24, 48, 96, 18
+    f80 = ctypes.c_float(80)
+    gp = torch.rand((B, N, C, P, P), device=DEV); ge = torch.rand((B, C, H, W), device=DEV)
+    res = []
+    try:
+        for mb in (1024, 0):
+            lib.omni_geometry_cache_clear()                            # the budget is read when a geometry builds its tables
+            L.set_option("bwd_table_mb", mb)
+            oe = torch.full((B, C, H, W), float("nan"), device=DEV); op = torch.full_like(gp, float("nan"))
+            assert lib.omni_equi2pers_bwd(P_(gp), P_(oe), 0, B, C, H, W, P, P, nrows, f80, f80, L.LAYOUT_BNCHW, None) == 0, lib.omni_last_error()
+            assert lib.omni_pers2equi_bwd(P_(ge), P_(op), 0, B, C, P, P, H, W, nrows, f80, f80, L.LAYOUT_BNCHW, None) == 0, lib.omni_last_error()
+            res.append((oe, op))
+    finally:
+        L.set_option("bwd_table_mb", 1024)
+        lib.omni_geometry_cache_clear()
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        assert bool(torch.isfinite(res[1][k]).all())
+        d = (res[0][k] - res[1][k]).abs().max().item()
+        assert d <= 2e-5 * max(1.0, res[0][k].abs().max().item()), (k, d)

@@ -8,7 +8,7 @@ found by measurement on MI355X:
 
  1. no packed-fp32 arithmetic (`v_pk_mul_f32`, `v_pk_add_f32`, `v_pk_fma_f32`) may be issued:
     `pers2equi`'s bilinear weights came out wrong in a 16-lane group while another stream's
-    convolution issued dense MFMAs (root cause unknown).  The switch that
+    convolution issued dense MFMAs (`v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` returns a wrong low product in lanes 48-63 then; profiles/r04g_pkfp32_rootcause.txt).  The switch that
     prevents it is a compiler flag in build.py — one object built without it, or a toolchain
     that ignores it, would re-open the hazard silently.  So the DISASSEMBLY is checked.
  2. the kernels that count their own `s_waitcnt vmcnt(N)` by hand (`e2p_box_kernel`,

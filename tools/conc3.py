@@ -44,7 +44,9 @@ noises = {
 from omnifusion_amd.equi_pers.equi2pers_v3 import equi2pers_patches
 rgb = torch.rand((B, 3, 512, 1024), device='cuda')
 noises['e2p (LDS path, has out-of-range lanes)'] = lambda: equi2pers_patches(rgb, 80, 4, 256, layout=lay)
+ONLY = os.environ.get("NOISE")
 for name, nz in noises.items():
+    if ONLY and not any(o in name for o in ONLY.split("|")): continue
     bad = 0; nb = 0
     for rep in range(10):
         with torch.cuda.stream(s2):

@@ -16,10 +16,15 @@ the master copy changed (`load_state_dict` — also through a wrapping `nn.DataP
 The forward is a launch sequence over libomnifusion_hip.so (see _engine.py); there is no autograd through the network
 (inference only, as test.py:197 runs the reference under torch.no_grad()): parameters have requires_grad=False and the
 module is constructed in eval mode; `train(True)` is accepted, but a forward in training mode raises (batch-statistics
-BatchNorm is not implemented).  Multi-GPU: one process per GPU shards the batch (omnifusion_amd/dist.py, bench.py);
-`nn.DataParallel` over SEVERAL devices in one process is rejected with a message, over one device it is a pass-through.
+BatchNorm is not implemented).  Multi-GPU: one process per GPU shards the batch (omnifusion_amd/dist.py, bench.py) — the
+fast way.  `nn.DataParallel` (test.py:105-111) works as well: over one device it is a pass-through; over several, every
+replica thread runs on a per-DEVICE execution context (packed weights, lanes) owned by the wrapped module and guarded by a
+lock (`_replicate_for_data_parallel`, `_device_context`) — replicas never share an Engine, and the packed weights are built
+once per device from the master copy, not from the parameter broadcast DataParallel repeats on every forward.
 """
+import contextlib
 import os
+import threading
 
 import torch
 from torch import nn
@@ -181,6 +186,13 @@ class _Pipelined:
         return _Pending(out, event, stream, input_read)
 
 
+class _DeviceContext:
+    """execution context of one device: packed weights (Engine), half-batch lanes, and the lock that serialises the
+    replica threads of an nn.DataParallel that share the device"""
+    def __init__(self, eng):
+        self.eng, self.lanes, self.version, self.lock = eng, None, -1, threading.RLock()
+
+
 class spherical_fusion(nn.Module):
     _ITERATIVE = False
     _want_input_event = False     # pipelined(): record an event when the forward has finished reading its input batch
@@ -199,6 +211,9 @@ class spherical_fusion(nn.Module):
         self._loaded = False          # a checkpoint has been loaded (the zero-initialised master copy is not a model)
         self._dirty = True            # packed buffers are out of date w.r.t. the master copy
         self._lanes = None
+        self._master_version = 0      # bumped whenever the master copy changes (load_state_dict, .cuda() / .to())
+        self.__dict__["_origin"] = None                  # a DataParallel replica: the wrapped module (plain attribute, not a submodule)
+        self._contexts, self._contexts_lock = {}, threading.Lock()       # per-device contexts of the replicas (shared with them)
         self.training = False         # inference module: constructed in eval mode
         self.register_load_state_dict_post_hook(spherical_fusion._after_load)
 
@@ -209,6 +224,7 @@ class spherical_fusion(nn.Module):
         if not incompatible_keys.missing_keys:
             module._loaded = True
         module._dirty = True
+        module._master_version += 1
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         sd = strip_module_prefix(state_dict)                               # train_erp_depth.py:307 saves through DataParallel
@@ -218,7 +234,54 @@ class spherical_fusion(nn.Module):
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
         self._dirty = True                                                 # .cuda() / .to(): repack on the new device
+        self._master_version = self.__dict__.get("_master_version", 0) + 1
         return out
+
+    # ---- nn.DataParallel over several devices (test.py:105-111).  torch replicates the module tree per forward: a replica is a
+    # shallow copy of __dict__ WITHOUT parameters (its state_dict() is empty, the broadcast copies are plain attributes) that runs
+    # on its own thread.  A replica therefore never packs and never touches the wrapped module's Engine: it borrows the execution
+    # context of ITS device from the wrapped module, under that context's lock.
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_origin"] = self.__dict__.get("_origin") or self
+        return replica
+
+    def _device_context(self, dev):
+        """(wrapped module only) the execution context of `dev`, its packed weights in step with the master copy"""
+        dev = torch.device(dev)
+        with self._contexts_lock:
+            ctx = self._contexts.get(dev)
+            if ctx is None:
+                ctx = self._contexts[dev] = _DeviceContext(None)
+        with ctx.lock:
+            if not self._loaded:
+                raise RuntimeError("no weights loaded: call load_state_dict() first")
+            if ctx.eng is None or ctx.version != self._master_version:
+                eng = Engine(self.nrows, self.npatches, self.patch_size, self.fov, self._ITERATIVE)
+                with torch.cuda.device(dev):
+                    eng.pack(nn.Module.state_dict(self), dev)
+                ctx.eng, ctx.lanes, ctx.version = eng, None, self._master_version
+        return ctx
+
+    @contextlib.contextmanager
+    def _execution(self, rgb):
+        """what a forward runs under: nothing for the module itself; for a DataParallel replica its device's context, locked,
+        bound to THIS replica object (a replica's __dict__ is its own, one thread uses it)"""
+        origin = self.__dict__.get("_origin")
+        if origin is None or not self.__dict__.get("_is_replica", False):
+            yield
+            return
+        if self.training:
+            raise NotImplementedError("spherical_fusion is inference-only (eval-mode BatchNorm folded into the weights): call .eval()")
+        self._eng.check_input(rgb)
+        ctx = origin._device_context(rgb.device)
+        with ctx.lock:
+            d = self.__dict__
+            d["_eng"], d["_lanes"], d["_loaded"], d["_dirty"], d["_pack_version"] = ctx.eng, ctx.lanes, True, False, ctx.version
+            try:
+                yield
+            finally:
+                ctx.lanes = d["_lanes"]
 
     def state_dict_schema(self):
         return schema(self.npatches, self._ITERATIVE)
@@ -241,7 +304,7 @@ class spherical_fusion(nn.Module):
         if rgb_device != dev:
             hint = ""
             if torch.cuda.device_count() > 1:
-                hint = " (nn.DataParallel over several devices in one process is not supported: run one process per GPU, omnifusion_amd/dist.py)"
+                hint = " (move the input to the model's device; nn.DataParallel scatters it per replica, omnifusion_amd/dist.py shards it per process)"
             raise ValueError(f"weights are on {dev}, input on {rgb_device}{hint}")
 
     def overflowed(self):
@@ -286,10 +349,18 @@ class spherical_fusion(nn.Module):
         if self.training:
             raise NotImplementedError("spherical_fusion is inference-only (eval-mode BatchNorm folded into the weights): call .eval()")
         self._eng.check_input(rgb)
+        if self.__dict__.get("_is_replica", False) and self.__dict__.get("_origin") is not None:
+            if self._eng.device != rgb.device:
+                raise RuntimeError("a DataParallel replica must run inside _execution()")
+            return                                                         # bound to its device's context by _execution()
         self._sync_packed(rgb.device)
 
     @torch.no_grad()
     def forward(self, rgb, confidence=True):
+        with self._execution(rgb):
+            return self._forward(rgb, confidence)
+
+    def _forward(self, rgb, confidence):
         self._check(rgb)
         e = self._eng
         bs, _, H, W = rgb.shape

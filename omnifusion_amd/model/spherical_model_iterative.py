@@ -23,6 +23,10 @@ class spherical_fusion(_single):
 
     @torch.no_grad()
     def forward(self, high_res, iter, confidence=False):
+        with self._execution(high_res):
+            return self._forward(high_res, iter, confidence)
+
+    def _forward(self, high_res, iter, confidence):
         self._check(high_res)
         e = self._eng
         bs, _, H, W = high_res.shape

@@ -598,6 +598,50 @@ def test_module_moves_and_dataparallel_wrapper():
     assert torch.equal(inner(torch.from_numpy(g["rgb"]).to(DEV)), out)
 
 
+def test_dataparallel_over_several_replicas_in_one_process():
+    """test.py:105-111 on a multi-GPU node: `nn.DataParallel(network)` scatters the batch over replica THREADS.  device_ids=[0, 0]
+    drives exactly that code path on one GPU (scatter -> replicate -> parallel_apply on two threads -> gather): the replicas run on
+    the device's execution context one after the other (its lock), never on a shared Engine; results are the bits of a plain call."""
+    from torch import nn
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    g = golden("G6_model_single")
+    inner = spherical_fusion(4, 18, (128, 128), (80, 80))
+    net = nn.DataParallel(inner, device_ids=[0, 0])
+    net.load_state_dict({"module." + k: v for k, v in make_state_dict(42, 18, False).items()})
+    net.cuda(); net.eval()
+    rgb1 = torch.from_numpy(g["rgb"]).to(DEV)
+    rgb = torch.cat([rgb1, rgb1.flip(3), rgb1.flip(2), rgb1], 0)            # 4 panoramas -> 2 + 2
+    plain = inner(rgb, confidence=True)
+    for _ in range(3):
+        out = net(rgb, confidence=True)
+        assert out.shape == plain.shape and torch.equal(out, plain)
+    assert np.abs(out[:1].cpu().numpy() - g["depth_conf"]).max() <= 1e-3
+    ctx = inner._contexts[torch.device("cuda", 0)]
+    assert ctx.eng is not inner._eng and ctx.version == inner._master_version
+    eng0 = ctx.eng
+    net(rgb, confidence=True)
+    assert inner._contexts[torch.device("cuda", 0)].eng is eng0            # packed once per device, not per forward
+    # a new checkpoint through the wrapper reaches the replicas' context
+    net.load_state_dict({"module." + k: v for k, v in make_state_dict(1, 18, False).items()})
+    out1 = net(rgb, confidence=True)
+    assert torch.equal(out1, inner(rgb, confidence=True)) and not torch.equal(out1, plain)
+    # ragged scatter (3 -> 2 + 1) and the iterative model (list outputs are gathered element-wise)
+    # (a lone panorama runs the latency plan: its bits are those of a plain single-panorama call, equal to the batched ones to 2e-5)
+    rag = net(rgb[:3], confidence=True)
+    assert torch.equal(rag[:2], inner(rgb[:2], confidence=True)) and torch.equal(rag[2:], inner(rgb[2:3], confidence=True))
+    g7 = golden("G7_model_iterative")
+    inner_it = spherical_fusion_it(4, 18, (128, 128), (80, 80))
+    net_it = nn.DataParallel(inner_it, device_ids=[0, 0])
+    net_it.load_state_dict({"module." + k: v for k, v in make_state_dict(42, 18, True).items()})
+    net_it.cuda(); net_it.eval()
+    r7 = torch.from_numpy(g7["rgb"]).to(DEV)
+    r7 = torch.cat([r7, r7.flip(3), r7.flip(2), r7], 0)
+    o = net_it(r7, iter=2)
+    p = inner_it(r7, iter=2)
+    assert len(o) == 2 and all(torch.equal(a, b) for a, b in zip(o, p))
+    assert np.abs(o[1][:1].cpu().numpy() - g7["it1"]).max() <= 1e-3
+
+
 def test_model_golden_fp32_precision_mode(monkeypatch):
     """README/DESIGN claim both precision modes pass the same golden: OMNI_NET_PRECISION=fp32 at MODEL level (VERDICT r1 weak #4)"""
     monkeypatch.setenv("OMNI_NET_PRECISION", "fp32")

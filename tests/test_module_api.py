@@ -84,3 +84,28 @@ def test_convert_model_like_traversal_is_a_no_op():
     net = spherical_fusion_it(6, 46, (128, 128), (80, 80))
     assert not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in net.modules())
     assert len(list(net.named_children())) > 10
+
+
+def test_dataparallel_replica_borrows_a_device_context_and_never_the_wrapped_engine():
+    """test.py:105-111 on a multi-GPU node: nn.DataParallel replicates the module per forward (`_replicate_for_data_parallel`: a shallow
+    __dict__ copy with NO parameters, one thread each).  A replica must not share the wrapped module's Engine nor pack from its own
+    (empty) state_dict: it points back at the wrapped module and takes its device's context from it (VERDICT r4 weak #2)."""
+    for cls, it in ((spherical_fusion, False), (spherical_fusion_it, True)):
+        net = cls(4, 18, (128, 128), (80, 80))
+        net.load_state_dict(make_state_dict(3, 18, it))
+        rep = net._replicate_for_data_parallel()
+        assert rep.__dict__["_origin"] is net and rep._is_replica and net.__dict__["_origin"] is None
+        assert "_origin" not in rep._modules and len(rep._parameters) == 0
+        rep2 = rep._replicate_for_data_parallel()                  # a replica of a replica still points at the real module
+        assert rep2.__dict__["_origin"] is net
+        assert rep._contexts is net._contexts                      # ONE table of per-device contexts, owned by the wrapped module
+        # the replica goes through _execution(): on a CPU tensor it fails like the module itself, before touching any engine
+        with pytest.raises(ValueError, match="no CPU path"):
+            rep(torch.zeros(1, 3, 32, 64), *((1,) if it else ()))
+        eng = net._eng
+        v = net._master_version
+        net.load_state_dict(make_state_dict(4, 18, it))
+        assert net._master_version == v + 1 and net._eng is eng    # contexts are re-packed lazily, by version
+    fresh = spherical_fusion(4, 18, (128, 128), (80, 80))
+    with pytest.raises(RuntimeError, match="no weights loaded"):
+        fresh._device_context("cuda:0")

@@ -110,45 +110,49 @@ struct ShConvArgs {
 // Fused epilogue of NT accumulator tiles of ONE pixel row r (D = W x pixels: a lane holds, per register quad q, the four
 // consecutive channels c0[j] + 8q + 4(lane>>5) .. +3 of its pixel).  Two phases: every bias / residual load is issued
 // before the first store, so the loads overlap instead of serialising load -> wait -> store once per quad.
-template <int NT>
+// QC: register quads of a tile whose loads are in flight together (4 = all; 2 where the register budget is tight)
+template <int NT, int QC = 4>
 __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r,
                                              const int (&c0)[NT], int lane, bool dst_sh)
 {
-    f4v bq[NT * 4], rf[NT * 4]; h4v rh[NT * 4], rl[NT * 4];
     const float* post = a.post ? a.post + (size_t)((unsigned)r % a.post_rows) * a.Cout : nullptr;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int q0 = 0; q0 < 4; q0 += QC) {
+        f4v bq[NT * QC], rf[NT * QC]; h4v rh[NT * QC], rl[NT * QC];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = c0[j] + 8 * q + 4 * (lane >> 5);
-            bq[j * 4 + q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + c) : (f4v)(0.0f);
-            if (a.res && a.res_f32) rf[j * 4 + q] = *reinterpret_cast<const f4v*>((const float*)a.res + r * a.Cout + c);
-            else if (a.res) {
-                const unsigned char* rp = (const unsigned char*)a.res + sh_off(r * a.Cout + c);
-                rh[j * 4 + q] = *reinterpret_cast<const h4v*>(rp); rl[j * 4 + q] = *reinterpret_cast<const h4v*>(rp + 64);
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) {
+                const int q = q0 + qq, c = c0[j] + 8 * q + 4 * (lane >> 5);
+                bq[j * QC + qq] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + c) : (f4v)(0.0f);
+                if (a.res && a.res_f32) rf[j * QC + qq] = *reinterpret_cast<const f4v*>((const float*)a.res + r * a.Cout + c);
+                else if (a.res) {
+                    const unsigned char* rp = (const unsigned char*)a.res + sh_off(r * a.Cout + c);
+                    rh[j * QC + qq] = *reinterpret_cast<const h4v*>(rp); rl[j * QC + qq] = *reinterpret_cast<const h4v*>(rp + 64);
+                }
             }
-        }
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = c0[j] + 8 * q + 4 * (lane >> 5);
-            f4v v;
+            for (int qq = 0; qq < QC; ++qq) {
+                const int q = q0 + qq, c = c0[j] + 8 * q + 4 * (lane >> 5);
+                f4v v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
-            v += bq[j * 4 + q];
-            if (a.res && a.res_f32) v += rf[j * 4 + q];
-            else if (a.res) v += sh_join4(rh[j * 4 + q], rl[j * 4 + q]);
-            if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            else if (a.act == OMNI_ACT_GELU) {
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[j][4 * q + e], 4.8828125e-4f, acc[j][4 * q + e]);
+                v += bq[j * QC + qq];
+                if (a.res && a.res_f32) v += rf[j * QC + qq];
+                else if (a.res) v += sh_join4(rh[j * QC + qq], rl[j * QC + qq]);
+                if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.act == OMNI_ACT_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                }
+                if (post) v += *reinterpret_cast<const f4v*>(post + c);
+                const size_t o = r * a.Cout + c;
+                if (dst_sh) act_store4<true>(a.dst, o, v);
+                else        act_store4<false>(a.dst, o, v);
             }
-            if (post) v += *reinterpret_cast<const f4v*>(post + c);
-            const size_t o = r * a.Cout + c;
-            if (dst_sh) act_store4<true>(a.dst, o, v);
-            else        act_store4<false>(a.dst, o, v);
-        }
+    }
 }
 
 // The same epilogue through LDS, for SH outputs (and SH or no residual): a wave's NT accumulator tiles of 32 CONSECUTIVE pixel rows
@@ -158,7 +162,10 @@ __device__ __forceinline__ void epilogue_row(const f16v (&acc)[NT], const f16v (
 // layer1's 75 MB, which is what its 23-us skeleton is made of.  Same operations on every element in the same order: same bits.
 // `tile` = 32 * (32 NT + 4) floats of LDS owned by this wave (the K loop's buffers, after a block barrier).
 // (r1: the pixel row of accumulator column 16 when the 32 columns are two runs of 16 consecutive rows — the stem's 2 x 16 tiles; default r0 + 16)
-template <int NT>
+// POST: the caller may carry a post-activation addend (a.post) — only the halo kernel does; the tile kernel compiles the addend's registers
+// away.  The tasks are processed HALF at a time (loads of a half issued together, then its arithmetic and stores): the live set is what lets
+// conv_sh_kernel<128,128,4,2,3,4> — twelve waves per block, a 168-register budget — run its epilogue without scratch (it carried 236 B).
+template <int NT, bool POST = true>
 __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f16v (&acc1)[NT], const ShConvArgs& a, size_t r0, int nrows,
                                                   const int (&c0)[NT], int lane, float* tile, size_t r1 = ~(size_t)0)
 {
@@ -178,48 +185,53 @@ __device__ __forceinline__ void epilogue_tile_lds(const f16v (&acc)[NT], const f
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (wave-private tile: the wave's own writes have landed)
     constexpr int TASKS = 32 * NT * 4 / 64;                       // (pixel, group, piece) tasks per lane
-    f4v va[TASKS], vb[TASKS], pa[TASKS], pb[TASKS]; h8v rh[TASKS], rl[TASKS];
-    size_t off[TASKS]; bool ok[TASKS];
+    constexpr int HALF = TASKS >= 4 ? TASKS / 2 : TASKS;          // tasks whose loads are in flight together
+    const bool post = POST && a.post != nullptr;
 #pragma unroll
-    for (int k = 0; k < TASKS; ++k) {
-        const int task = k * 64 + lane, px = task / (4 * NT), rem = task - px * (4 * NT), j = rem >> 2, pc = rem & 3;
-        ok[k] = px < nrows;
-        va[k] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc);
-        vb[k] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc + 4);
-        off[k] = ((px < 16 ? r0 + px : r1 + (px - 16)) * a.Cout + c0[j]) * 4 + 16 * pc;     // byte offset of the hi piece (the lo piece: + 64)
-        if (a.bias) { va[k] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc); vb[k] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc + 4); }
-        if (a.res && ok[k]) {
-            rh[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k]);
-            rl[k] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[k] + 64);
+    for (int k0 = 0; k0 < TASKS; k0 += HALF) {
+        f4v va[HALF], vb[HALF], pa[HALF], pb[HALF]; h8v rh[HALF], rl[HALF];
+        size_t off[HALF]; bool ok[HALF];
+#pragma unroll
+        for (int kk = 0; kk < HALF; ++kk) {
+            const int task = (k0 + kk) * 64 + lane, px = task / (4 * NT), rem = task - px * (4 * NT), j = rem >> 2, pc = rem & 3;
+            ok[kk] = px < nrows;
+            va[kk] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc);
+            vb[kk] = *reinterpret_cast<const f4v*>(tile + px * PITCH + 32 * j + 8 * pc + 4);
+            off[kk] = ((px < 16 ? r0 + px : r1 + (px - 16)) * a.Cout + c0[j]) * 4 + 16 * pc;     // byte offset of the hi piece (the lo piece: + 64)
+            if (a.bias) { va[kk] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc); vb[kk] += *reinterpret_cast<const f4v*>(a.bias + c0[j] + 8 * pc + 4); }
+            if (a.res && ok[kk]) {
+                rh[kk] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[kk]);
+                rl[kk] = *reinterpret_cast<const h8v*>((const unsigned char*)a.res + off[kk] + 64);
+            }
+            if (post && ok[kk]) {                                 // added AFTER the activation, as in epilogue_row
+                const float* pp = a.post + (size_t)((unsigned)(px < 16 ? r0 + px : r1 + (px - 16)) % a.post_rows) * a.Cout + c0[j] + 8 * pc;
+                pa[kk] = *reinterpret_cast<const f4v*>(pp); pb[kk] = *reinterpret_cast<const f4v*>(pp + 4);
+            }
         }
-        if (a.post && ok[k]) {                                    // added AFTER the activation, as in epilogue_row
-            const float* pp = a.post + (size_t)((unsigned)(px < 16 ? r0 + px : r1 + (px - 16)) % a.post_rows) * a.Cout + c0[j] + 8 * pc;
-            pa[k] = *reinterpret_cast<const f4v*>(pp); pb[k] = *reinterpret_cast<const f4v*>(pp + 4);
+#pragma unroll
+        for (int kk = 0; kk < HALF; ++kk) {
+            if (!ok[kk]) continue;
+            f4v v0 = va[kk], v1 = vb[kk];
+            if (a.res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] += fmaf((float)rl[kk][e], 4.8828125e-4f, (float)rh[kk][e]); v1[e] += fmaf((float)rl[kk][4 + e], 4.8828125e-4f, (float)rh[kk][4 + e]); }
+            }
+            if (a.act == OMNI_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+            } else if (a.act == OMNI_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = 0.5f * v0[e] * (1.0f + erff(v0[e] * 0.70710678118654752440f)); v1[e] = 0.5f * v1[e] * (1.0f + erff(v1[e] * 0.70710678118654752440f)); }
+            }
+            if (post) { v0 += pa[kk]; v1 += pb[kk]; }
+            h4v h0, l0, h1, l1;
+            sh_split4(v0, h0, l0); sh_split4(v1, h1, l1);
+            h8v oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oh[e] = h0[e]; oh[4 + e] = h1[e]; ol[e] = l0[e]; ol[4 + e] = l1[e]; }
+            *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[kk]) = oh;
+            *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[kk] + 64) = ol;
         }
-    }
-#pragma unroll
-    for (int k = 0; k < TASKS; ++k) {
-        if (!ok[k]) continue;
-        f4v v0 = va[k], v1 = vb[k];
-        if (a.res) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] += fmaf((float)rl[k][e], 4.8828125e-4f, (float)rh[k][e]); v1[e] += fmaf((float)rl[k][4 + e], 4.8828125e-4f, (float)rh[k][4 + e]); }
-        }
-        if (a.act == OMNI_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
-        } else if (a.act == OMNI_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = 0.5f * v0[e] * (1.0f + erff(v0[e] * 0.70710678118654752440f)); v1[e] = 0.5f * v1[e] * (1.0f + erff(v1[e] * 0.70710678118654752440f)); }
-        }
-        if (a.post) { v0 += pa[k]; v1 += pb[k]; }
-        h4v h0, l0, h1, l1;
-        sh_split4(v0, h0, l0); sh_split4(v1, h1, l1);
-        h8v oh, ol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { oh[e] = h0[e]; oh[4 + e] = h1[e]; ol[e] = l0[e]; ol[4 + e] = l1[e]; }
-        *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[k]) = oh;
-        *reinterpret_cast<h8v*>((unsigned char*)a.dst + off[k] + 64) = ol;
     }
 }
 
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int r0 = row0 + wm * (BM / WM) + i * 32;
-            if (r0 < a.rows) epilogue_tile_lds<TN>(acc[i], acc1[i], a, (size_t)r0, min(32, a.rows - r0), c0, lane, tile);
+            if (r0 < a.rows) epilogue_tile_lds<TN, false>(acc[i], acc1[i], a, (size_t)r0, min(32, a.rows - r0), c0, lane, tile);
             if (i + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the tile is read back before it is written again)
         }
         return;
@@ -505,10 +517,20 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
                     *reinterpret_cast<f4v*>(a.ws + ((size_t)blockIdx.y * a.rows + r) * a.Cout + c) = v;
                 }
         } else {
-            int c0[TN];
+            if constexpr (NL > 0 && TN > 1) {
+                // twelve waves per block = a 168-register budget: one channel tile at a time (4 instead of 4 TN bias / residual quads in flight)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c0[j] = col0 + wn * (BN / WN) + j * 32;
-            epilogue_row<TN>(acc[i], acc1[i], a, (size_t)r, c0, lane, a.dst_sh != 0);
+                for (int j = 0; j < TN; ++j) {
+                    const f16v ea[1] = {acc[i][j]}, eb[1] = {acc1[i][j]};
+                    const int cj[1] = {col0 + wn * (BN / WN) + j * 32};
+                    epilogue_row<1, 2>(ea, eb, a, (size_t)r, cj, lane, a.dst_sh != 0);
+                }
+            } else {
+                int c0[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c0[j] = col0 + wn * (BN / WN) + j * 32;
+                epilogue_row<TN>(acc[i], acc1[i], a, (size_t)r, c0, lane, a.dst_sh != 0);
+            }
         }
     }
 }

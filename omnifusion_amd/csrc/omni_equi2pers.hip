@@ -1253,7 +1253,11 @@ void fill_args(E2PArgs& a, const omni_geometry* g, const void* erp, void* pers, 
     a.ixy = g->e2p_ixy;
     a.dbg = 0; a.trace = nullptr;
     a.store_mode = omni_options().e2p_store;
-    a.dbg_skip_fb = omni_options().e2p_ref_lds == 2;
+#ifdef OMNI_DEBUG_BUILD
+    a.dbg_skip_fb = omni_options().e2p_ref_lds == 2;     // (a RESULT-changing timing experiment: the debug build only, like every OMNI_*_DBG bit)
+#else
+    a.dbg_skip_fb = 0;
+#endif
 #ifdef OMNI_DEBUG_BUILD
     a.dbg = omni_debug_bits("OMNI_E2P_DBG");
     a.trace = omni_debug_trace_buf();
@@ -1499,10 +1503,10 @@ int e2p_work_table(const omni_geometry* gc, int planes, int nbmax, hipStream_t s
     std::vector<uint4> tab(mx * 8, make_uint4(0u, 0u, 0u, 0u));
     for (int x = 0; x < 8; ++x) for (size_t i = 0; i < col[x].size(); ++i) tab[i * 8 + x] = col[x][i];
     if (tab.empty()) OMNI_FAIL(OMNI_ERR_INVALID, "omni_equi2pers: empty work table");
+    if (tt.work.size() >= 256) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: more than 256 distinct plane counts / option sets on one geometry handle (omni_geometry_cache_clear() drops them)");
     uint4* dev = nullptr;
     OMNI_HIP(hipMalloc((void**)&dev, sizeof(uint4) * tab.size()));
     if (hipMemcpy(dev, tab.data(), sizeof(uint4) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); OMNI_FAIL(OMNI_ERR_HIP, "omni_equi2pers: work table upload"); }
-    if (tt.work.size() >= 256) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_equi2pers: more than 256 distinct plane counts / option sets on one geometry handle (omni_geometry_cache_clear() drops them)");
     // a table lives as long as its geometry handle (omni_geometry.hip frees them with it; a handle a hipGraph holds is pinned and never
     // destroyed): a launch in flight on another stream, or a captured graph, may hold the pointer — never freed here (the FIFO
     // that was here freed tables under running kernels).  A table is 16 B per block, ~100 KB; one per plane count seen.

@@ -15,6 +15,8 @@
 #include <zlib.h>
 #include <string.h>
 #include <atomic>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 #include "omni_internal.h"
@@ -28,7 +30,9 @@ inline unsigned be32(const unsigned char* p) { return ((unsigned)p[0] << 24) | (
 int channels_of(int ctype) { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0; }
 
 // walks the chunks: fills `info`, the palette, and inflates the concatenated IDAT payloads into `raw` (filter byte + samples per scan line)
-int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsigned char>& raw, unsigned char (*pal)[3], int* npal, bool info_only)
+// (expect_w / expect_h > 0: the destination's size — a header that announces anything else is refused BEFORE a byte is allocated for it)
+int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsigned char>& raw, unsigned char (*pal)[3], int* npal, bool info_only,
+               int expect_w = 0, int expect_h = 0)
 {
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (n < 8 + 25 || memcmp(d, sig, 8) != 0) OMNI_FAIL(OMNI_ERR_INVALID, "png: not a PNG stream");
@@ -45,6 +49,7 @@ int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsi
         if ((size_t)len > n - pos - 12) { rc = OMNI_ERR_INVALID; omni_set_error("png: truncated chunk"); break; }
         if (be32(body + len) != (unsigned)crc32(crc32(0L, Z_NULL, 0), type, len + 4)) { rc = OMNI_ERR_INVALID; omni_set_error("png: chunk CRC mismatch"); break; }
         if (!memcmp(type, "IHDR", 4)) {
+            if (have_ihdr) { rc = OMNI_ERR_INVALID; omni_set_error("png: a second IHDR chunk"); break; }
             if (len != 13) { rc = OMNI_ERR_INVALID; omni_set_error("png: bad IHDR"); break; }
             info.w = (int)be32(body); info.h = (int)be32(body + 4); info.depth = body[8]; info.ctype = body[9]; info.interlace = body[12];
             have_ihdr = true;
@@ -52,13 +57,20 @@ int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsi
             if (info_only) { done = true; break; }
             if (info.interlace != 0) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: interlaced (Adam7) files are not supported"); break; }
             if (!(info.depth == 8 || (info.depth == 16 && info.ctype != 3))) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: only 8- and 16-bit samples are supported"); break; }
-            const size_t stride = (size_t)info.w * channels_of(info.ctype) * (info.depth / 8);
-            rawsize = (stride + 1) * (size_t)info.h;
+            // the header is untrusted input: the sizes are checked (against the destination, and against 2 GiB in 64-bit arithmetic —
+            // w, h < 2^31 and <= 8 bytes per pixel cannot wrap it) before anything is allocated for them
+            if ((expect_w > 0 && info.w != expect_w) || (expect_h > 0 && info.h != expect_h)) {
+                rc = OMNI_ERR_INVALID;
+                omni_set_error("png: the image is " + std::to_string(info.h) + " x " + std::to_string(info.w) + ", the destination " + std::to_string(expect_h) + " x " + std::to_string(expect_w));
+                break;
+            }
+            const unsigned long long stride = (unsigned long long)info.w * channels_of(info.ctype) * (info.depth / 8);
+            if (stride + 1 > 0x7fffffffull || (stride + 1) * (unsigned long long)info.h > 0x7fffffffull) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: image too large (2 GiB of samples or more)"); break; }
+            rawsize = (size_t)((stride + 1) * (unsigned long long)info.h);
             raw.resize(rawsize);
             if (inflateInit(&zs) != Z_OK) { rc = OMNI_ERR_HIP; omni_set_error("png: inflateInit failed"); break; }
             inflating = true;
-            zs.next_out = raw.data(); zs.avail_out = (uInt)std::min<size_t>(rawsize, 0x7fffffffu);
-            if (rawsize > 0x7fffffffu) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: image too large"); break; }
+            zs.next_out = raw.data(); zs.avail_out = (uInt)rawsize;
         } else if (!have_ihdr) {
             rc = OMNI_ERR_INVALID; omni_set_error("png: IHDR is not the first chunk"); break;
         } else if (!memcmp(type, "PLTE", 4)) {
@@ -66,6 +78,7 @@ int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsi
             *npal = (int)(len / 3);
             memcpy(pal, body, len);
         } else if (!memcmp(type, "IDAT", 4)) {
+            if (len == 0) { pos += 12; continue; }                 // an empty IDAT is legal (cv2.imread reads such files): nothing to inflate
             zs.next_in = const_cast<unsigned char*>(body); zs.avail_in = len;
             const int zr = inflate(&zs, Z_NO_FLUSH);
             if (zr != Z_OK && zr != Z_STREAM_END) { rc = OMNI_ERR_INVALID; omni_set_error("png: corrupt zlib stream"); break; }
@@ -124,15 +137,15 @@ int png_unfilter(std::vector<unsigned char>& raw, int h, size_t stride, int bpp)
 }
 
 // kind 0: cv2.imread(path) -> uint8 BGR [H,W,3];  kind 1: cv2.imread(path, -1) of a single-channel file -> uint8 / uint16 [H,W] in host byte order
-int png_decode(const unsigned char* d, size_t n, void* dst, int H, int W, int kind, int* elem_bytes)
+int png_decode_body(const unsigned char* d, size_t n, void* dst, int H, int W, int kind, int* elem_bytes)
 {
+    if (H <= 0 || W <= 0) OMNI_FAIL(OMNI_ERR_INVALID, "png: the destination must have a positive size");
     PngInfo info{};
     std::vector<unsigned char> raw;
     unsigned char pal[256][3];
     int npal = 0;
-    int rc = png_unpack(d, n, info, raw, pal, &npal, false);
+    int rc = png_unpack(d, n, info, raw, pal, &npal, false, W, H);
     if (rc != OMNI_OK) return rc;
-    if (info.w != W || info.h != H) OMNI_FAIL(OMNI_ERR_INVALID, "png: the image is " + std::to_string(info.h) + " x " + std::to_string(info.w) + ", the destination " + std::to_string(H) + " x " + std::to_string(W));
     const int ch = channels_of(info.ctype), bs = info.depth / 8, bpp = ch * bs;
     const size_t stride = (size_t)W * bpp;
     rc = png_unfilter(raw, H, stride, bpp);
@@ -165,6 +178,18 @@ int png_decode(const unsigned char* d, size_t n, void* dst, int H, int W, int ki
     }
     return OMNI_OK;
 }
+
+// no exception leaves the decoder: it runs behind extern "C" entry points and on std::thread workers, where one would end the process
+int png_decode(const unsigned char* d, size_t n, void* dst, int H, int W, int kind, int* elem_bytes)
+{
+    try {
+        return png_decode_body(d, n, dst, H, W, kind, elem_bytes);
+    } catch (const std::bad_alloc&) {
+        OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: out of host memory while decoding");
+    } catch (const std::exception& e) {
+        OMNI_FAIL(OMNI_ERR_INVALID, std::string("png: ") + e.what());
+    }
+}
 }  // namespace
 
 extern "C" int omni_png_info(const void* data, size_t nbytes, int* width, int* height, int* bit_depth, int* color_type)
@@ -173,7 +198,9 @@ extern "C" int omni_png_info(const void* data, size_t nbytes, int* width, int* h
     PngInfo info{};
     std::vector<unsigned char> raw;
     int npal = 0;
-    const int rc = png_unpack((const unsigned char*)data, nbytes, info, raw, nullptr, &npal, true);
+    int rc;
+    try { rc = png_unpack((const unsigned char*)data, nbytes, info, raw, nullptr, &npal, true); }
+    catch (const std::exception& e) { OMNI_FAIL(OMNI_ERR_INVALID, std::string("png: ") + e.what()); }
     if (rc != OMNI_OK) return rc;
     if (width) *width = info.w;
     if (height) *height = info.h;

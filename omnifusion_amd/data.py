@@ -124,6 +124,9 @@ class DeviceFeeder:
         with torch.cuda.stream(self.side):
             s["dev"][:src.shape[0]].copy_(src, non_blocking=True)      # async H2D on the side stream
             s["ready"].record(self.side)
+            if src is frames and hasattr(self.batches, "recycle"):     # a producer with a buffer ring (png.PngBatches): the page-locked
+                ev = torch.cuda.Event(); ev.record(self.side)          # batch may be decoded into again once this copy has run
+                self.batches.recycle(frames, ev)
         s["src"] = src                                                 # keep the host buffer alive until the copy has been ordered
         s["n"] = int(src.shape[0])                                     # (a DataLoader with drop_last=False ends on a shorter batch)
 

@@ -29,6 +29,12 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 FORBIDDEN = re.compile(r"\bv_pk_(mul|add|fma)_f32\b")
 # kernels whose correctness depends on hand-counted vmcnt: no scratch, no spills
 COUNTED = ("e2p_box_kernel", "p2e_lds_kernel", "p2e_walk_kernel", "e2p_ref_kernel")
+# kernels that hold >= 1 % of the bench's GPU time (profiles/r04e_bench_kernel_stats.txt): a spill there is a performance bug —
+# scratch 0 is required of every instantiation (conv_sh_kernel<128,128,4,2,3,4> carried 236 B of it)
+HOT = ("conv_sh_kernel", "conv3x3_halo_sh_kernel", "conv3x3_up2_g1_kernel", "stem_f16x3_pc_kernel", "heads_kernel", "maxpool_kernel",
+       "layernorm512_kernel", "attention_kernel", "upsample_sh8_kernel")
+# the translation units WITHOUT device code (host-only): every other object must yield a code object, or the check fails
+HOST_ONLY = ("omni_png.o", "omni_geometry.o")
 
 
 def _device_object(obj, tmp):
@@ -92,12 +98,20 @@ def objects():
 def check(objs=None):
     """Returns the list of violations (empty = fine)."""
     bad = []
+    found = {c: 0 for c in COUNTED + HOT}
+    full = objs is None                                              # the whole library: every guarded kernel must be SEEN
     for obj in objs or objects():
         base = os.path.basename(obj)
         if not os.path.exists(obj):
             bad.append(f"{base}: object missing (build first)")
             continue
         asm = disassemble(obj)
+        if not asm.strip():
+            # fail CLOSED: an object that yields no device code is either a known host-only unit or a sign that the extraction broke
+            # (objcopy / bundler / target string) — in which case nothing below would have been checked at all
+            if base not in HOST_ONLY:
+                bad.append(f"{base}: no gfx950 device code could be extracted (not in HOST_ONLY): the ISA rules were NOT checked")
+            continue
         cur = "?"
         for line in asm.splitlines():
             if line.endswith(">:"):
@@ -106,10 +120,21 @@ def check(objs=None):
                 bad.append(f"{base}: packed-fp32 instruction in {cur}: {line.strip()[:80]}")
                 break
         for k in kernel_meta(obj):
+            for c in COUNTED + HOT:
+                if c in k["name"]:
+                    found[c] += 1
             if any(c in k["name"] for c in COUNTED):
                 if k.get("scratch", 0) or k.get("vgpr_spill", 0):          # (SGPR spills go to VGPR lanes — v_writelane — not to memory)
                     bad.append(f"{base}: {k['name']} uses scratch {k.get('scratch')} B / spills {k.get('vgpr_spill')} VGPR "
                                f"{k.get('sgpr_spill')} SGPR — its hand-counted s_waitcnt vmcnt(N) would be off")
+            elif any(c in k["name"] for c in HOT):
+                if k.get("scratch", 0) or k.get("vgpr_spill", 0):
+                    bad.append(f"{base}: {k['name']} (a kernel with >= 1 % of the bench's GPU time) uses scratch {k.get('scratch')} B / "
+                               f"spills {k.get('vgpr_spill')} VGPR")
+    if full:
+        for c, n in found.items():
+            if n == 0:                                              # a rename, or a change of the notes format: the rule would be silently off
+                bad.append(f"guarded kernel `{c}` was not found in any code object's metadata: the scratch rule for it was NOT checked")
     return bad
 
 
@@ -129,7 +154,7 @@ if __name__ == "__main__":
         v = check()
         for line in v:
             print("ISA CHECK FAILED:", line)
-        print("isa check:", "FAILED" if v else "ok (no v_pk_*_f32; counted-wait kernels without scratch)")
+        print("isa check:", "FAILED" if v else "ok (no v_pk_*_f32; counted-wait and hot kernels without scratch; every guarded kernel found)")
         sys.exit(1 if v else 0)
     print(f"{'object':22s} {'vgpr':>4s} {'agpr':>4s} {'sgpr':>4s} {'lds':>6s} {'scr':>4s}  kernel")
     for o, nm, v, a, s, l, sc in table():

@@ -73,25 +73,60 @@ class PngBatches:
 
     def __init__(self, paths, batch, threads=0, pinned=True, ring=3):
         self.paths, self.batch, self.threads, self.pinned, self.ring = list(paths), int(batch), int(threads), pinned, max(2, int(ring))
+        self._pool, self._pool_lock = [], None                     # buffers handed back by the consumer: (tensor, event or None)
 
     def __len__(self):
         return (len(self.paths) + self.batch - 1) // self.batch
+
+    def recycle(self, buf, event=None):
+        """The consumer is done with `buf` (a batch this iterable yielded) once `event` has completed (None: now): the producer decodes a
+        later batch into it instead of page-locking fresh memory (`DeviceFeeder` calls this with the event behind its H2D copy).  Without
+        this call every batch gets a buffer of its own, as a DataLoader's would."""
+        import threading
+        if self._pool_lock is None:
+            self._pool_lock = threading.Lock()
+        with self._pool_lock:
+            if len(self._pool) < self.ring + 2:
+                self._pool.append((buf, event))
+
+    def _buffer(self, n):
+        if self._pool_lock is None:
+            return None
+        with self._pool_lock:
+            for i, (buf, ev) in enumerate(self._pool):
+                if buf.shape[0] == n and (ev is None or ev.query()):
+                    del self._pool[i]
+                    return buf
+        return None
 
     def __iter__(self):
         import queue
         import threading
         q = queue.Queue(maxsize=self.ring - 1)
         stop = threading.Event()
+        if self._pool_lock is None:
+            self._pool_lock = threading.Lock()
+
+        def put(item):                                             # never blocks past `stop`: an abandoned iterator must not strand this thread
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def producer():
             try:
                 for k in range(0, len(self.paths), self.batch):
                     if stop.is_set():
                         return
-                    q.put(decode_batch(self.paths[k:k + self.batch], pinned=self.pinned, threads=self.threads))
-                q.put(None)
+                    chunk = self.paths[k:k + self.batch]
+                    if not put(decode_batch(chunk, pinned=self.pinned, threads=self.threads, out=self._buffer(len(chunk)))):
+                        return
+                put(None)
             except Exception as e:              # surfaces in the consumer
-                q.put(e)
+                put(e)
         th = threading.Thread(target=producer, daemon=True)
         th.start()
         try:
@@ -104,3 +139,9 @@ class PngBatches:
                 yield item
         finally:
             stop.set()
+            try:                                                   # drop what was decoded ahead (pinned batches), let the producer see `stop`
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=5.0)

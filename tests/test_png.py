@@ -126,3 +126,56 @@ def test_damaged_and_unsupported_files_are_refused():
     files = [good, good[:40]]
     with pytest.raises(ValueError, match="image 1"):
         png.decode_batch(files)
+
+
+def _with_ihdr(good, w, h, depth=8, ctype=2):
+    """`good` with its IHDR rewritten (CRC fixed): the header announces a size the data does not have"""
+    body = struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)
+    return good[:8] + _chunk(b"IHDR", body) + good[8 + 25:]
+
+
+def test_hostile_headers_cost_nothing_and_legal_oddities_decode():
+    """the IHDR is untrusted — its size is checked against the destination (and 2 GiB) BEFORE a byte is allocated for it, a second
+    IHDR is refused, no exception crosses the C ABI; a zero-length IDAT chunk is legal PNG (cv2.imread reads such files)."""
+    a = RNG.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    good = encode_png(a, 2, 8, idat=1)
+    huge = _with_ihdr(good, 0x7fffffff, 0x7fffffff, 16, 6)                        # 2^65 bytes of samples announced by a 100-byte file
+    assert png.png_info(huge)[:2] == (0x7fffffff, 0x7fffffff)                     # (info only parses)
+    out = np.empty((8, 8, 3), np.uint8)
+    from omnifusion_amd import _lib
+    import ctypes
+    for blob, H, W in ((huge, 8, 8), (_with_ihdr(good, 16, 8), 8, 8), (_with_ihdr(good, 46341, 46341), 46341, 46341)):
+        rc = _lib.load().omni_png_decode(blob, ctypes.c_size_t(len(blob)), out.ctypes.data_as(ctypes.c_void_p), H, W, 0)
+        assert rc != 0                                                            # refused with a status, the process lives
+    with pytest.raises(ValueError, match="destination 8 x 8"):
+        png.decode_batch([good, _with_ihdr(good, 16, 8)])
+    twice = good[:8 + 25] + good[8:8 + 25] + good[8 + 25:]
+    with pytest.raises(ValueError, match="second IHDR"):
+        png.imread(twice)
+    ihdr_end = 8 + 25
+    empty_idat = good[:ihdr_end] + _chunk(b"IDAT", b"") + good[ihdr_end:-12] + _chunk(b"IDAT", b"") + good[-12:]
+    assert np.array_equal(png.imread(empty_idat), a[:, :, ::-1])
+
+
+def test_png_batches_abandoned_iterator_and_buffer_recycling():
+    import threading
+    import time
+    frames = [RNG.integers(0, 256, (16, 32, 3), dtype=np.uint8) for _ in range(12)]
+    files = [encode_png(f, 2, 8, idat=2) for f in frames]
+    before = threading.active_count()
+    it = iter(png.PngBatches(files, 2, threads=2, pinned=False, ring=2))
+    first = next(it)
+    assert np.array_equal(first[1].numpy(), frames[1][:, :, ::-1])
+    it.close()                                                                    # the consumer leaves early: the producer must not stay blocked in put()
+    t0 = time.time()
+    while threading.active_count() > before and time.time() - t0 < 5:
+        time.sleep(0.05)
+    assert threading.active_count() == before
+    pb = png.PngBatches(files, 3, threads=2, pinned=False, ring=3)
+    seen, ptrs = [], set()
+    for b in pb:
+        seen.append(b.numpy().copy())
+        ptrs.add(b.data_ptr())
+        pb.recycle(b)                                                             # done with it at once: later batches reuse the buffers
+    assert np.array_equal(np.concatenate(seen), np.stack([f[:, :, ::-1] for f in frames]))
+    assert len(ptrs) < len(seen)

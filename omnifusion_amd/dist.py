@@ -37,6 +37,64 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_local_cpus(index):
+    """CPUs of the NUMA node the GPU `index` hangs off (sysfs `local_cpulist` of its PCI function), or None when unknown."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as fh:
+            cpus = _parse_cpulist(fh.read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def cpus_for_rank(local, nlocal, allowed, gpu_cpus=None):
+    """The CPU set of local rank `local` of `nlocal`: the ranks whose GPUs share a NUMA node split that node's allowed CPUs into
+    contiguous, disjoint chunks (a rank enqueues ~60 k launches/s: its launch thread must neither migrate nor share a core with
+    another rank's); without topology information the allowed CPUs are split evenly.  `gpu_cpus[j]`: CPUs local to GPU j, or None.
+    Never returns an empty set (more ranks than CPUs: chunks wrap)."""
+    allowed = sorted(allowed)
+    if not allowed or nlocal < 1:
+        return set(allowed)
+    mine = None
+    if gpu_cpus is not None and local < len(gpu_cpus) and gpu_cpus[local]:
+        mine = tuple(c for c in gpu_cpus[local] if c in set(allowed))
+    if mine:
+        peers = [j for j in range(nlocal) if j < len(gpu_cpus) and gpu_cpus[j] and
+                 tuple(c for c in gpu_cpus[j] if c in set(allowed)) == mine]
+        pool, k, m = list(mine), peers.index(local), len(peers)
+    else:
+        pool, k, m = allowed, local % nlocal, nlocal
+    lo, hi = k * len(pool) // m, (k + 1) * len(pool) // m
+    return set(pool[lo:hi]) if hi > lo else {pool[k % len(pool)]}
+
+
+def bind_rank(local, nlocal):
+    """Pin this rank to its CPU chunk (see cpus_for_rank); OMNI_BIND_CPUS=0 disables.  Returns the set bound to, or None."""
+    if os.environ.get("OMNI_BIND_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = os.sched_getaffinity(0)
+        topo = [_gpu_local_cpus(j) for j in range(nlocal)] if torch.cuda.is_available() and torch.cuda.device_count() >= nlocal else None
+        cpus = cpus_for_rank(local, nlocal, allowed, topo)
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except OSError:
+        return None
+
+
 def init(backend=None):
     """Join the process group the launcher described.  backend None -> "nccl" (= RCCL on ROCm) when a GPU is
     visible, else "gloo".  With nccl, LOCAL_RANK is the device index (one rank per GPU) and the group is bound
@@ -52,6 +110,8 @@ def init(backend=None):
         local_dev = local % ndev                     # gloo: several ranks may share a GPU (single-GPU test boxes)
         torch.cuda.set_device(local_dev)
         device = torch.device("cuda", local_dev)
+    if world > 1 and "LOCAL_WORLD_SIZE" in os.environ:      # under the launcher: one rank per GPU, each on its GPU's NUMA node
+        bind_rank(local, int(os.environ["LOCAL_WORLD_SIZE"]))
     # under a launcher (WORLD_SIZE set) the group is created even for ONE rank: the RCCL bring-up, the barrier and the MAX
     # all-reduce of the timing protocol then run on a single-GPU box exactly as they do on eight
     if (world > 1 or "WORLD_SIZE" in os.environ) and not dist.is_initialized():

@@ -34,8 +34,10 @@ full = dist.gather_batch(torch.from_numpy(state["out"]), B)
 sd = {"a.weight": torch.arange(6, dtype=torch.float32).reshape(2, 3), "a.n": torch.tensor(7)} if rank == 0 else None
 sd = dist.broadcast_state_dict(sd, src=0)
 assert sd["a.weight"].tolist() == [[0, 1, 2], [3, 4, 5]] and int(sd["a.n"]) == 7 and list(sd) == ["a.weight", "a.n"]
+cpus = [None] * world
+torch.distributed.all_gather_object(cpus, sorted(os.sched_getaffinity(0))) if world > 1 else cpus.__setitem__(0, sorted(os.sched_getaffinity(0)))
 if rank == 0:
     np.save(out_path + ".npy", full.numpy())
     with open(out_path, "w") as fh:
-        json.dump({"world": world, "dt": dt, "shard0": [lo, hi]}, fh)
+        json.dump({"world": world, "dt": dt, "shard0": [lo, hi], "cpus": cpus}, fh)
 dist.finalize()

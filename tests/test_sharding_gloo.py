@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 from omnifusion_amd import dist          # noqa: E402
 
 
-@pytest.mark.parametrize("world,B", [(2, 4), (2, 5)])
+@pytest.mark.parametrize("world,B", [(2, 4), (2, 5), (8, 64)])       # (8, 64): BASELINE cfg 4's literal split, 8 panoramas per rank
 def test_two_rank_sharding_matches_single_rank(tmp_path, world, B):
     out = str(tmp_path / "probe.json")
     cmd = dist.launch_command(os.path.join(ROOT, "tests", "_rank_probe.py"), [str(B), out], world)
@@ -29,6 +29,8 @@ def test_two_rank_sharding_matches_single_rank(tmp_path, world, B):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     info = json.load(open(out))
     assert info["world"] == world and info["shard0"] == list(dist.shard(B, 0, world))
+    assert sorted(c for cs in info["cpus"] for c in cs) == sorted(set(c for cs in info["cpus"] for c in cs)) or world > (os.cpu_count() or 1)
+    assert all(len(cs) >= 1 for cs in info["cpus"]) and len(info["cpus"]) == world      # every rank bound to a CPU chunk of its own
     # 3 timed steps; the slowest rank sleeps world*10 ms per step: MAX over ranks, not the mean or rank 0's time
     assert info["dt"] >= 3 * 0.01 * world
     from oracle import c_oracle as co
@@ -36,6 +38,24 @@ def test_two_rank_sharding_matches_single_rank(tmp_path, world, B):
     full, _, _, _ = co.equi2pers(erp, 80, 4, 8)
     ref = co.pers2equi(full, 80, 4, 8, (32, 64))
     assert np.array_equal(np.load(out + ".npy"), ref)                 # bitwise shard equivalence, ragged split included
+
+
+def test_rank_cpu_binding_follows_the_gpu_topology():
+    """each rank's launch thread is pinned to a chunk of the CPUs of ITS GPU's NUMA node (sysfs local_cpulist), the ranks
+    of one node get disjoint chunks; without topology the allowed CPUs are split evenly; never an empty set."""
+    allowed = set(range(64))
+    numa = [list(range(0, 32))] * 4 + [list(range(32, 64))] * 4                   # 8 GPUs, 4 per socket
+    sets = [dist.cpus_for_rank(r, 8, allowed, numa) for r in range(8)]
+    assert all(len(s) == 8 for s in sets) and set().union(*sets) == allowed
+    assert all(sets[r] <= set(numa[r]) for r in range(8))
+    assert all(sets[a].isdisjoint(sets[b]) for a in range(8) for b in range(a + 1, 8))
+    even = [dist.cpus_for_rank(r, 8, allowed, None) for r in range(8)]
+    assert even[0] == set(range(8)) and even[7] == set(range(56, 64))
+    # a cgroup that allows only part of a node; a GPU with unknown locality falls back to the even split
+    part = [dist.cpus_for_rank(r, 2, set(range(4, 12)), [list(range(0, 16)), None]) for r in range(2)]
+    assert part[0] == set(range(4, 12)) and part[1] == set(range(8, 12))
+    assert dist.cpus_for_rank(5, 8, {3}, None) == {3} and dist.cpus_for_rank(2, 4, {0, 1}, None) != set()
+    assert dist._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
 
 
 def test_shard_bounds_cover_batch_exactly():

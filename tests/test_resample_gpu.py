@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import assert_outliers_at_mask_edges, count_flipped_pixels, golden, rng_uniform, smooth_erp, assert_close_outliers
+from _util import assert_outliers_at_mask_edges, count_flipped_pixels, golden, pin_outliers, rng_uniform, smooth_erp, assert_close_outliers
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +46,12 @@ P2E_FLIPS = {
 }
 
 
+# Samples at which equi2pers misses the reference (goldens) / the oracle by more than 1e-3 on i.i.d. inputs (a bilinear tap one pixel off where
+# the sampling coordinate sits within round-off of an integer: polar longitudes).  Counts measured on MI355X in round 5, pinned like P2E_FLIPS.
+E2P_OUTLIERS = {
+}
+
+
 # ------------------------------------------------------------------ golden vectors
 @pytest.mark.parametrize("name", ["G1_equi2pers_n4", "G2_equi2pers_n6", "G2b_equi2pers_n3",
                                   "G2b_equi2pers_n5", "G2c_equi2pers_rect"])
@@ -57,6 +63,7 @@ def test_equi2pers_golden(name):
     assert pers.shape == g["pers"].shape and pers.is_contiguous() and pers.device.type == "cuda"
     assert cp.device.type == "cpu"
     assert_close_outliers(pers.cpu().numpy(), g["pers"], tol=1e-3, max_tol=2e-2, frac=2e-5, what=name)
+    pin_outliers(name, pers.cpu().numpy(), g["pers"], 1e-3, E2P_OUTLIERS)
     np.testing.assert_allclose(xyz.cpu().numpy(), g["xyz"], atol=1e-4)
     np.testing.assert_allclose(uv.cpu().numpy(), g["uv"], atol=1e-4)
     np.testing.assert_array_equal(cp.numpy(), g["center_p"])
@@ -98,6 +105,7 @@ def test_known_answers_config1_golden():
     g = golden("G8_config1")
     pers, xyz, uv, cp = equi2pers(t(rng_uniform(100, (1, 3, 512, 1024))), (80, 80), 4, (256, 256))
     assert_close_outliers(pers.cpu().numpy()[:, :, ::8, ::8, :], g["pers_sub"], tol=1e-3, max_tol=2e-2, frac=5e-5)
+    pin_outliers("G8_config1", pers.cpu().numpy()[:, :, ::8, ::8, :], g["pers_sub"], 1e-3, E2P_OUTLIERS)
     np.testing.assert_allclose(xyz.cpu().numpy()[:, :, ::8, ::8], g["xyz_sub"], atol=1e-4)
     np.testing.assert_allclose(uv.cpu().numpy()[:, :, ::8, ::8], g["uv_sub"], atol=1e-4)
     e = pers2equi(t(rng_uniform(101, (1, 1, 256, 256, 18))), (80, 80), 4, (256, 256), (512, 1024), "x").cpu().numpy()
@@ -106,6 +114,7 @@ def test_known_answers_config1_golden():
     g3 = golden("G8_config3")
     p3, _, _, _ = equi2pers(t(rng_uniform(102, (1, 1, 1024, 2048))), (80, 80), 6, (256, 256))
     assert_close_outliers(p3.cpu().numpy()[:, :, ::8, ::8, :], g3["pers_sub"], tol=1e-3, max_tol=5e-2, frac=1e-4)
+    pin_outliers("G8_config3", p3.cpu().numpy()[:, :, ::8, ::8, :], g3["pers_sub"], 1e-3, E2P_OUTLIERS)
     e3 = pers2equi(t(rng_uniform(103, (1, 1, 256, 256, 46))), (80, 80), 6, (256, 256), (1024, 2048), "x").cpu().numpy()
     assert_close_outliers(e3[:, :, ::8, ::8], g3["erp_sub"], tol=2e-4, max_tol=0.51, frac=1e-4)
     assert len(g3["erp_nan_idx"]) <= 8 and np.isfinite(e3).all()      # reference NaN pixels (q11) stay finite here
@@ -129,6 +138,7 @@ def test_equi2pers_vs_oracle(cfg):
     refn, _, _, _ = co.equi2pers(xn, (80, 80), nrows, (P, P))
     got = equi2pers_patches(t(xn), (80, 80), nrows, (P, P))
     assert_close_outliers(got.cpu().numpy(), refn, tol=1e-3, max_tol=5e-2, frac=5e-5, what=str(cfg))
+    pin_outliers(cfg, got.cpu().numpy(), refn, 1e-3, E2P_OUTLIERS)
 
 
 @pytest.mark.parametrize("cfg", [(2, 1, 512, 1024, 4, 256), (1, 2, 1024, 2048, 6, 256), (3, 3, 250, 500, 5, 64),
@@ -243,6 +253,7 @@ def test_benched_planar_launches_vs_oracle(P):
     refn, _, _, _ = co.equi2pers(xn, (80, 80), nrows, (P, P))
     gotn = equi2pers_patches(t(xn), (80, 80), nrows, (P, P), layout=L.LAYOUT_BNCHW)
     assert_close_outliers(gotn.cpu().numpy(), pl(refn), tol=1e-3, max_tol=5e-2, frac=5e-5, what=f"equi2pers planar P={P}")
+    pin_outliers(("planar", B, H, W, nrows, P), gotn.cpu().numpy(), pl(refn), 1e-3, E2P_OUTLIERS)
     # pers2equi on the patches the operator chain really sees (consistent patches: strict) and on i.i.d. noise (outlier gate)
     d = ref[:, :1]
     e_ref = co.pers2equi(d, (80, 80), nrows, (P, P), (H, W))
@@ -280,6 +291,7 @@ def test_high_res_config5_vs_oracle(dtype):
     # (the samples next to the two poles see the ill-conditioned longitude of SURVEY 8d: 1.3e-6 of the samples differ by up to 4e-3
     #  between ANY two fp32 evaluations at this ERP width; everything else is within the strict gate)
     assert_close_outliers(got.float().cpu().numpy(), want, tol=tol, max_tol=2e-2, frac=1e-5, what="cfg5 equi2pers")
+    pin_outliers(("cfg5", dtype), got.float().cpu().numpy(), want, tol, E2P_OUTLIERS)
     e_ref = co.pers2equi(np.transpose(want, (0, 2, 3, 4, 1)), (80, 80), 6, (P, P), (H, W))
     pin = t(np.ascontiguousarray(want)).to(dt)
     if dtype == "float16":

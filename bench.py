@@ -208,17 +208,21 @@ def png_fed_rate(run, depth, dev, B, src_hw, nfiles, budget_s, pending):
     Hs, Ws = src_hw
     base = synthetic_photo(Hs, Ws, 900)
     files = [encode_png_bgr(np.roll(base, (131 * k, 517 * k), axis=(0, 1))) for k in range(nfiles)]     # distinct files, one synthesis
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    t0 = time.perf_counter()                                                  # the decode pool alone (no GPU work): its ceiling
-    nb = 0
-    while time.perf_counter() - t0 < min(2.0, budget_s / 3):
-        png.decode_batch([files[(nb * B + i) % nfiles] for i in range(B)], threads=0)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    probe = png.PngBatches([files[i % nfiles] for i in range(B * 64)], B, threads=0, pinned=True)
+    workers = probe.workers
+    t0, nb = time.perf_counter(), 0                                           # the decode pool alone (no GPU work): the loader's ceiling
+    for buf in probe:
+        probe.recycle(buf)
         nb += 1
+        if time.perf_counter() - t0 > min(2.0, budget_s / 3):
+            break
     pool_rate = nb * B / (time.perf_counter() - t0)
-    per_s = pool_rate * 1.5                                                    # enough batches for ~budget_s at the slower of pool and GPU
+    del probe
+    per_s = pool_rate * 1.2                                                    # enough batches for ~budget_s at the slower of pool and GPU
     nbatch = max(12, int(min(per_s, 4000.0) * budget_s / B))
     paths = [files[i % nfiles] for i in range(nbatch * B)]
-    feeder = DeviceFeeder(png.PngBatches(paths, B, threads=0, pinned=True, ring=4), (ERP_H, ERP_W), device=dev, out_buffers=2 if depth > 1 else 1)
+    feeder = DeviceFeeder(png.PngBatches(paths, B, threads=0, pinned=True), (ERP_H, ERP_W), device=dev, out_buffers=2 if depth > 1 else 1)
     nskip, nret, tf = min(4 * max(depth, 2), nbatch // 3), 0, None
     for frame_rgb in feeder:
         p_ = run(frame_rgb, confidence=True)
@@ -237,8 +241,8 @@ def png_fed_rate(run, depth, dev, B, src_hw, nfiles, budget_s, pending):
     rate = B * (nbatch - nskip) / (time.perf_counter() - tf)
     raw_mb = Hs * Ws * 3 / 1e6
     return {"panoramas_per_s_per_gpu": rate, "file_size": [Hs, Ws], "file_MB": float(np.mean([len(f) for f in files])) / 1e6, "decoded_MB": raw_mb,
-            "decode_threads": threads, "decode_pool_alone_panoramas_per_s": pool_rate, "decode_MBps_per_thread": pool_rate * raw_mb / threads,
-            "batches": nbatch}
+            "host_threads": ncpu, "decode_workers": workers, "decode_threads_busy": workers * B,          # (a PNG is one deflate stream: one thread per image)
+            "decode_pool_alone_panoramas_per_s": pool_rate, "decode_MBps_per_thread": pool_rate * raw_mb / (workers * B), "batches": nbatch}
 
 
 def pmc_traffic(B, name="resample_traffic.json"):

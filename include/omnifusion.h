@@ -207,6 +207,23 @@ int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void*
                                  const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                  int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                                  const float* post, size_t post_elems, omni_stream_t stream);
+/* omni_conv2d_sh_f16x3_ws whose split-K reduction happens INSIDE the launch (replaces the second pass the reference never
+ * needed: one cuDNN call per Conv3d, model/spherical_model.py:259-261,270-302).  `tickets`: ntickets zero-initialised 32-bit counters owned by
+ * the caller's execution context (launches sharing them must be stream-ordered; the kernel leaves them zero); ws: omni_conv2d_sk_ws_bytes()
+ * bytes.  The launch is a 1-D grid of (tile, K segment) units; all segments of a tile run on ONE XCD, leave their partial tiles in its L2 and
+ * the last to arrive sums them in segment order and runs the epilogue: the bits of the two-launch form with the same splitk.  Without
+ * tickets (NULL), with a smaller workspace or with option conv_sk = 0 the two-launch form runs. */
+int omni_conv2d_sh_f16x3_sk_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
+                               const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
+                               int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
+                               unsigned* tickets, size_t ntickets, omni_stream_t stream);
+size_t omni_conv2d_sk_ws_bytes(long long rows, int Cout, int splitk);
+/* split factor for a caller WITH tickets: (tile, segment) units sized to fill the 256 CUs from one launch (rows = the NOMINAL row count, as for
+ * omni_conv2d_splitk_plan: the factor must not depend on the batch).  KH .. pad: the launch's shape — 1 where the launch takes a halo kernel. */
+int omni_conv2d_sk_plan(long long rows, int Cout, int ksteps, int KH, int KW, int stride, int pad, int H, int W);
+/* *violations = 1 if a block of an in-launch reduction ever found itself on another XCD than its block id implies (the premise of the
+ * hand-over through one XCD's L2; checked by every block against the hardware's XCC_ID).  Synchronises: diagnostic only. */
+int omni_conv_sk_status(int* violations, int reset);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a

@@ -1588,6 +1588,38 @@ extern "C" size_t omni_conv2d_sk_ws_bytes(long long rows, int Cout, int splitk)
     if (rows <= 0 || Cout <= 0 || splitk <= 1) return 0;
     return std::max(sk_ws_bytes(rows, Cout, splitk), (size_t)splitk * (size_t)rows * Cout * sizeof(float));    // (also enough for the two-launch form)
 }
+extern "C" int omni_conv2d_splitk_plan(long long rows, int Cout, int ksteps);            // omni_conv.hip: the two-launch plan
+
+// Split factor for a caller with tickets.  Cost model in K-steps of a 128-row tile: a launch is ceil(units / 256) rounds of one unit per CU,
+// a unit costs its K segment + FIX (prologue, pipeline fill, partial tile out), the last arrival REDUCE more; a split must buy >= 10 %.
+// (rows = the nominal row count: the factor — and with it every output bit — must not depend on the batch.)
+extern "C" int omni_conv2d_sk_plan(long long rows, int Cout, int ksteps, int KH, int KW, int stride, int pad, int H, int W)
+{
+    const int two = omni_conv2d_splitk_plan(rows, Cout, ksteps);
+    const int mode = omni_options().conv_sk_plan;
+    if (mode == 0 || !omni_options().conv_sk || rows <= 0 || Cout <= 0 || ksteps < 8) return two;
+    // launches that take a halo kernel when unsplit stay unsplit (conv2d_sh_impl's conditions)
+    const bool s1 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && !omni_options().conv_nohalo;
+    const bool halo_img = s1 && H == W && (W == 16 || (W == 8 && omni_options().conv_img >= 2)) && Cout % 64 == 0 && omni_options().conv_img > 0;
+    const bool halo_wide = s1 && W % 32 == 0 && H % 4 == 0;
+    if (two <= 1 && (halo_img || halo_wide)) return 1;
+    const int smax = std::min(32, ksteps / 4);
+    if (mode > 1) return std::max(1, std::min(mode, smax));
+    const int bn = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
+    const long long tiles = ((rows + 127) / 128) * (Cout / bn);
+    const double FIX = 8.0, REDUCE = 3.0;
+    auto cost = [&](int s) {
+        const long long rounds = (tiles * s + 255) / 256;
+        return rounds * ((ksteps + s - 1) / s + FIX) + (s > 1 ? REDUCE + 0.25 * s : 0.0);
+    };
+    int best = 1;
+    double cb = cost(1) * 0.9;                                     // a split must buy >= 10 %
+    for (int s = 2; s <= smax; ++s)
+        if (cost(s) < cb) { cb = cost(s); best = s; }
+    if (const int cap = omni_options().splitk_max; cap > 0 && best > cap) best = cap;
+    return best;
+}
+
 // sticky flag of the in-launch reduction's premise (hardware block b runs on XCD b % 8): *violations = 1 if any block ever found itself on another XCD
 // (results of that launch may be wrong); synchronises — a diagnostic entry point like omni_sh_overflow
 extern "C" int omni_conv_sk_status(int* violations, int reset)

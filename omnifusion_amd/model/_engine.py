@@ -156,9 +156,13 @@ class Engine:
         """sticky range flag of the split-half format on this engine's device (omni_sh_overflow); synchronises"""
         if self.device is None:
             return False
-        flag = ctypes.c_int(0)
+        flag, viol = ctypes.c_int(0), ctypes.c_int(0)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().omni_sh_overflow(ctypes.byref(flag), 1 if reset else 0), "sh_overflow")
+            _lib.check(_lib.load().omni_conv_sk_status(ctypes.byref(viol), 1 if reset else 0), "conv_sk_status")
+        if viol.value:
+            raise RuntimeError("a convolution block ran on another XCD than its block id implies: the in-launch split-K reduction hands partial tiles over "
+                               "through ONE XCD's L2 and its results may be wrong on this device / partition mode — rerun with OMNI_CONV_SK=0")
         return bool(flag.value)
 
     # ------------------------------------------------------------------ operator shims
@@ -170,7 +174,7 @@ class Engine:
         Wo = (Wd + 2 * pad - k) // stride + 1
         if out is None:
             out = torch.empty((M, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-        S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device)
+        S, ws, nb = self._splitk(M * Ho * Wo, Cout, k * k * (C1 + C2) // 32, x.device, shape=(k, k, stride, pad, H, Wd))
         b = _p(self.w[key + ".b"]) if bias else None
         late_post = None
         if post is not None and (S > 1 or not self.sh or out_f32):
@@ -183,8 +187,10 @@ class Engine:
                                                   _p(post), ctypes.c_size_t(post.numel()), self._s)
         elif self.sh:
             lat = 4 if (self._bs == 1 and self.latency_plan) else 0     # fmt bit 2: a lone panorama keeps the im2col tiles for 16-wide images
-            rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), (0 if out_f32 else 1) | lat,
-                                             M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
+            tk, ntk = self._sk_tickets(M * Ho * Wo, Cout, x.device) if (S > 1 and self.in_launch_reduce) else (None, 0)
+            rc = lib.omni_conv2d_sh_f16x3_sk_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), (0 if out_f32 else 1) | lat,
+                                                M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb),
+                                                _p(tk), ctypes.c_size_t(ntk), self._s)
         else:
             rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), b, _p(res), _p(out), M, H, Wd, C1, C2, Cout,
                                              k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
@@ -199,7 +205,23 @@ class Engine:
     latency_plan = True
     rows_gemm = True           # ... and its transformer GEMMs (18 rows) take the register-streaming kernel
 
-    def _splitk(self, rows, Cout, ksteps, device):
+    # Split-K launches of the f16x3 path: 0 (default) two launches (partial sums + sh_splitk_reduce_kernel) | 1: the reduction INSIDE the launch
+    # (omni_conv2d_sh_f16x3_sk_ws; same plan, same bits) | 2: ... with the plan that sizes (tile, segment) units for the 256 CUs (omni_conv2d_sk_plan:
+    # other split factors, other bits).  Built for VERDICT r4 #1 and measured SLOWER on MI355X (profiles/r05a_sk_conv.txt): kept as a switch.
+    in_launch_reduce = int(os.environ.get("OMNI_IN_LAUNCH_REDUCE", "0"))
+
+    def _sk_tickets(self, rows, Cout, device):
+        """arrival counters of the in-launch split-K reduction: zero-initialised, left zero by every launch, one buffer per execution context
+        (= per stream); grown buffers keep their predecessors alive (a captured hipGraph may still point at them)"""
+        need = ((rows + 63) // 64) * (Cout // 32) + 8
+        tk = getattr(self, "_tk", None)
+        if tk is None or tk.numel() < need or tk.device != device:
+            if tk is not None:
+                self._tk_retired = getattr(self, "_tk_retired", []) + [tk]
+            self._tk = tk = torch.zeros(max(need, 16384), dtype=torch.int32, device=device)
+        return tk, tk.numel()
+
+    def _splitk(self, rows, Cout, ksteps, device, shape=None):
         """Split factor planned for a NOMINAL batch (not the actual one), so that the K summation order — and with it
         every output bit — is the same whether a panorama is processed inside a batch of 2 or of 64 (image-sharded
         multi-GPU runs reproduce single-GPU results bit for bit).  A LONE panorama (BASELINE cfg 2) is latency-bound —
@@ -208,10 +230,18 @@ class Engine:
         batched ones to 2e-5 abs instead of bit for bit (`Engine.latency_plan = False` restores the one plan for all)."""
         plan_batch = self.SINGLE_BATCH if (self._bs == 1 and self.latency_plan) else self.NOMINAL_BATCH
         rows_plan = rows // self._bs * plan_batch
-        S = int(_lib.load().omni_conv2d_splitk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps))
+        lib = _lib.load()
+        if self.sh and self.in_launch_reduce >= 2:                 # (tile, segment) units sized for the 256 CUs
+            KH, KW, stride, pad, H, W = shape if shape is not None else (1, 1, 1, 0, 1, 1)
+            S = int(lib.omni_conv2d_sk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps, KH, KW, stride, pad, H, W))
+        else:
+            S = int(lib.omni_conv2d_splitk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps))
         if S <= 1:
             return 1, None, 0
-        ws, nb = self._workspace(S * rows * Cout * 4, device)
+        if self.sh and self.in_launch_reduce:
+            ws, nb = self._workspace(int(lib.omni_conv2d_sk_ws_bytes(ctypes.c_longlong(rows), Cout, S)), device)
+        else:
+            ws, nb = self._workspace(S * rows * Cout * 4, device)
         return S, ws, nb
 
     def _workspace(self, nbytes, device):
@@ -258,9 +288,10 @@ class Engine:
                                                    1 if out_sh else 0, rows, K, Nout, act, self._s), "gemm " + w16key)
             return out
         S, ws, nb = (1, None, 0) if K <= 512 else self._splitk(rows, Nout, K // 32, x.device)
-        rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), None, _p(self.w[w16key]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
-                                         (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws),
-                                         ctypes.c_size_t(nb), self._s)
+        tk, ntk = self._sk_tickets(rows, Nout, x.device) if (S > 1 and self.in_launch_reduce) else (None, 0)
+        rc = lib.omni_conv2d_sh_f16x3_sk_ws(_p(x), None, _p(self.w[w16key]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
+                                            (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws),
+                                            ctypes.c_size_t(nb), _p(tk), ctypes.c_size_t(ntk), self._s)
         _lib.check(rc, "gemm " + w16key)
         return out
 

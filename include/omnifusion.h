@@ -200,6 +200,16 @@ int omni_gemm_rows_ln_sh_f16x3(const float* x, const float* ln_weight, const flo
  * 2Wl % 32 == 0 and 2Hl % 4 == 0 (else OMNI_ERR_UNSUPPORTED: omni_upsample_bilinear_sh + omni_conv2d_sh_f16x3_ws give the same bits). */
 int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, const float* bias, void* dst, int fmt,
                               int M, int Hl, int Wl, int C, int Cout, int act, omni_stream_t stream);
+/* de_conv4_0 AND the two heads in one pass over the widest tensor of the network (model/spherical_model.py:300-307: F.interpolate + ConvBnReLU 32 -> 32,
+ * then pred (ReLU) / weight_pred (sigmoid), 3x3, 32 -> 1, and their product): a = relu(pred(y)) * (confidence ? sigmoid(weight_pred(y)) : 1),
+ * c = sigmoid(weight_pred(y)); y = de_conv4_0's output never exists.  src SH [M,P/2,P/2,32]; heads_w16f from omni_heads_pack_f16x3; scratch of
+ * omni_up2_heads_scratch_bytes(M, P) bytes; out_a / out_c planar [M,P,P] (out_c may be NULL).  Equal to omni_conv3x3_up2_sh_f16x3 + omni_heads_f32 up to
+ * the fp32 summation order of the heads (whose products run f16x3 here).  Deterministic. */
+size_t omni_up2_heads_scratch_bytes(int M, int P);
+int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16, const float* bias, const void* heads_w16f, float bias_pred, float bias_weight,
+                                    float* scratch, size_t scratch_bytes, float* out_a, float* out_c, int M, int P, int confidence, omni_stream_t stream);
+/* w [2][9][32] fp32 (HOST memory) -> the 4 KB fragment-ordered f16x3 operand of omni_conv3x3_up2_heads_sh_f16x3 (HOST memory; copy it to the device). */
+int omni_heads_pack_f16x3(const float* w_host, void* dst_host);
 /* omni_conv2d_sh_f16x3_ws with `post` (fp32, post_elems = whole rows of Cout channels) added AFTER the activation, output row index
  * modulo its row count: `layer1 + point_feat` (model/spherical_model.py:258; point_feat [N,h,w,64] broadcast over the batch, or
  * full size) inside layer1's last convolution.  post = NULL: the plain operator.  Not combinable with split-K. */

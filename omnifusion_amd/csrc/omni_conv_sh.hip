@@ -887,7 +887,21 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 //   waves 4-7, producers: source pixels global -> registers -> up-sampling arithmetic -> the halo of tile k+1 in LDS (two halo buffers);
 //   waves 0-3, consumers: 54 matrix instructions per wave on the halo of tile k, bias from registers, stores — never a wait on memory.
 // One block barrier per tile hands the buffers over.  Same cells, same K order (ky, kx, k chunk): same bits as the kernel it replaces.
-__global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int ntiles)
+//
+// HEADS (round 5): the `pred` / `weight_pred` heads (3x3, 32 -> 1 each, model/spherical_model.py:223-224,304-306) start HERE instead of in a kernel
+// that re-reads this one's output: de_conv4_0's result is the widest tensor of the network (302 MB at 8 panoramas, written once and read once by
+// heads_kernel: 290 us for the pair) and never exists in this form.  out[q] = sum_{dy,dx} w[dy][dx] . x[q + (dy,dx)] is turned around: pixel p, where
+// x[p] lives in registers, contributes w[dy][dx] . x[p] to q = p - (dy,dx) — eighteen 32-channel dot products per pixel (9 taps x 2 heads), which are
+// ONE more matrix product: rows = (dy, head, dx), k = the 32 channels in the order the accumulator quads already hold them (a lane's 16 channels
+// are its two k chunks: no data movement), three f16x3 terms like every other product = 6 matrix instructions per wave and tile beside the 54 of
+// the convolution.  The three dx terms of a row are summed across neighbouring lanes (fixed order dx = -1, 0, +1), which leaves per tile row and
+// (dy, head) 34 partial sums — pixels -1 .. 32: the two outer ones belong to the neighbouring tiles' pixels — written to `hr`
+// [tile][row 4][(dy, head) 6][34]: 3.3 KB per tile instead of 16 KB.  heads_finish_kernel adds the three rows (dy) and the neighbour tiles'
+// outer sums in a fixed order, then bias, ReLU / sigmoid and the product.  Deterministic; equal to heads_kernel up to fp32 summation order.
+struct HeadsArgs { const void* w16; float* hr; };           // w16: the heads' weights in fragment order (Engine: heads.w16f), [hi kc0, hi kc1, lo kc0, lo kc1][64 lanes] x 16 B
+
+template <bool HEADS>
+__global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int ntiles, HeadsArgs hd)
 {
     constexpr int BN = 32, TH = 4, NW = 4, RPP = 8 * NW;
     constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
@@ -920,6 +934,11 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
         f4v bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + 8 * q + 4 * (lane >> 5)) : (f4v)(0.0f);
+        h8v hwf[4];                                              // HEADS: this lane's weight fragments (row lane & 31, k chunk lane >> 5)
+        if constexpr (HEADS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hwf[k] = *reinterpret_cast<const h8v*>((const unsigned char*)hd.w16 + k * 1024 + lane * 16);
+        }
         int ao[9], fo[4];                                        // fragment offsets, as in conv3x3_halo_sh_kernel
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -975,6 +994,43 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
             }
             __builtin_amdgcn_sched_barrier(0);
             if (OMNI_ABL(8192)) { acc += accy; acc1 += accx; }
+            if constexpr (HEADS) {
+                // the tile's result stays in registers: v[q] = channels 8q + 4h .. + 3 of pixel lane & 31 — the lane's k chunk kc is its quads 2kc, 2kc + 1
+                h8v ph[2], pl[2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f4v v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * q + e], 4.8828125e-4f, acc[4 * q + e]);
+                    v += bq[q];
+                    if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    h4v hi, lo; sh_split4(v, hi, lo);            // (the split every SH epilogue does: range guard included)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ph[q >> 1][4 * (q & 1) + e] = hi[e]; pl[q >> 1][4 * (q & 1) + e] = lo[e]; }
+                }
+                f16v d0 = (f16v)(0.0f), d1 = (f16v)(0.0f);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwf[kc], ph[kc], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwf[2 + kc], ph[kc], d1, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwf[kc], pl[kc], d1, 0, 0, 0);
+                }
+                // rows (reg & 3) + 8 (reg >> 2) + 4 h: register group g = 0..2 is (dy, head) pair g + 3h, its registers 0..2 are dx = -1, 0, +1
+                const int px = lane & 31, h = lane >> 5;
+                float* hp = hd.hr + ((size_t)tile * TH + wave) * (6 * 34);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float tl = fmaf(d1[4 * g], 4.8828125e-4f, d0[4 * g]), tc = fmaf(d1[4 * g + 1], 4.8828125e-4f, d0[4 * g + 1]),
+                                tr = fmaf(d1[4 * g + 2], 4.8828125e-4f, d0[4 * g + 2]);
+                    // out[q] takes w[dx] . x[q + dx]: its dx = -1 term comes from pixel q - 1, its dx = +1 term from pixel q + 1
+                    const float fl = __shfl_up(tl, 1, 32), fr = __shfl_down(tr, 1, 32);
+                    const float sum = ((px > 0 ? fl : 0.0f) + tc) + (px < 31 ? fr : 0.0f);
+                    float* row = hp + (g + 3 * h) * 34;
+                    row[1 + px] = sum;
+                    if (px == 0) row[0] = tr;                      // pixel -1 of this row (the left neighbour tile's column 31) takes my dx = +1 term
+                    if (px == 31) row[33] = tl;                    // pixel 32 takes my dx = -1 term
+                }
+            } else
             {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave (through an LDS transposition, split-half or
                 // fp32: 247 | 248 us — the stores are not this kernel's limit, and 18 KB of LDS more per block are felt beside other kernels)
                 int m, y0, x0; origin(tile, m, y0, x0);
@@ -1323,6 +1379,36 @@ __global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restr
         __syncthreads();                                          // this image buffer is free, the other one is complete
         b ^= 1;
     }
+}
+
+// Second half of the fused heads (see conv3x3_up2_g1_kernel<HEADS>): one thread per output pixel adds, for each head, the partial sums of the three
+// source rows (dy = -1, 0, +1: row y + dy of its tile, (dy, head) plane, position 1 + x % 32) and, at a tile's first / last column, the outer sums
+// of the horizontally neighbouring tile (positions 33 / 0) — in that fixed order — then heads_kernel's own tail (bias, ReLU, sigmoid, product).
+__global__ __launch_bounds__(256) void heads_finish_kernel(const float* __restrict__ hr, float bp, float bw, float* __restrict__ outa, float* __restrict__ outc,
+                                                           int M, int P, int conf)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * P * P) return;
+    const int x = (int)(i % P), y = (int)((i / P) % P), m = (int)(i / ((size_t)P * P));
+    const int tw = P / HT_W, th = P / 4, c = x & 31;
+    float s[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int py = y + dy;
+        if ((unsigned)py >= (unsigned)P) continue;
+        const size_t tile = ((size_t)m * th + (py >> 2)) * tw + (x >> 5);
+        const float* rowp = hr + (tile * 4 + (py & 3)) * (6 * 34) + (dy + 1) * 2 * 34;
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd) {
+            s[hd] += rowp[hd * 34 + 1 + c];
+            if (c == 0 && x > 0) s[hd] += rowp[hd * 34 + 33 - 4 * 6 * 34];          // the left neighbour tile's pixel 32
+            if (c == 31 && x + 1 < P) s[hd] += rowp[hd * 34 + 4 * 6 * 34];          // the right neighbour tile's pixel -1
+        }
+    }
+    const float ap = s[0] + bp, aw = s[1] + bw;
+    const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
+    outa[i] = conf ? pr * cf : pr;
+    if (outc) outc[i] = cf;
 }
 
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
@@ -1765,13 +1851,69 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
     a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
     const int grid = M * (H / 4) * (W / HT_W);
     if (C == 32 && Cout == 32 && omni_options().conv_up2_persist) {    // de_conv4_0: resident weights, one persistent block of 8 waves per CU
-        hipLaunchKernelGGL(conv3x3_up2_g1_kernel, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid);
+        hipLaunchKernelGGL(conv3x3_up2_g1_kernel<false>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid, HeadsArgs{nullptr, nullptr});
         OMNI_HIP(hipGetLastError());
         return OMNI_OK;
     }
     if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
     else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, true>), dim3(grid * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, a);
     OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// de_conv4_0 + the two heads (model/spherical_model.py:300-307): a = relu(pred(y)) (* sigmoid(weight_pred(y)) when confidence), c = sigmoid(weight_pred(y)),
+// y = relu(conv3x3(up2(src)) + bias) with 32 -> 32 channels — y never exists (conv3x3_up2_g1_kernel<HEADS> + heads_finish_kernel, see there).
+// src SH [M, P/2, P/2, 32]; wt16 / bias: de_conv4_0's; heads_w16f: 4 KB, the heads' [2][9][32] weights in the fragment order of omni_heads_pack_f16x3;
+// scratch: omni_up2_heads_scratch_bytes(M, P) bytes; out_a / out_c planar [M, P, P] (out_c may be NULL).  P % 32 == 0.
+// Equal to omni_conv3x3_up2_sh_f16x3 (fp32 output) + omni_heads_f32 up to fp32 summation order (the heads' products run f16x3: ~1e-6 relative).
+extern "C" size_t omni_up2_heads_scratch_bytes(int M, int P)
+{
+    if (M <= 0 || P <= 0 || P % 32) return 0;
+    return (size_t)M * (P / 4) * (P / 32) * 4 * 6 * 34 * sizeof(float);
+}
+extern "C" int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16, const float* bias, const void* heads_w16f, float bias_pred, float bias_weight,
+                                               float* scratch, size_t scratch_bytes, float* out_a, float* out_c, int M, int P, int confidence, omni_stream_t stream)
+{
+    if (!src || !wt16 || !heads_w16f || !scratch || !out_a) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_up2_heads_sh: null pointer");
+    if (M <= 0 || P <= 0 || P % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_up2_heads_sh: the patch size must be a multiple of 32");
+    if (scratch_bytes < omni_up2_heads_scratch_bytes(M, P)) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_up2_heads_sh: scratch too small (omni_up2_heads_scratch_bytes)");
+    if ((long long)M * P * P >= (1ll << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv3x3_up2_heads_sh: tensor too large for 32-bit indices");
+    ShConvArgs a;
+    a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = nullptr; a.dst_sh = 0; a.res_f32 = 0;
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.wt_major = 0; a.epi_lds = 0;
+    a.M = M; a.H = P; a.W = P; a.C1 = 32; a.C2 = 0; a.Cout = 32; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = OMNI_ACT_RELU;
+    a.Ho = P; a.Wo = P; a.rows = M * P * P; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1; a.sk_tickets = nullptr; a.sk_tp = 0;
+    const int grid = M * (P / 4) * (P / HT_W);
+    hipLaunchKernelGGL(conv3x3_up2_g1_kernel<true>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid, HeadsArgs{heads_w16f, scratch});
+    OMNI_HIP(hipGetLastError());
+    const size_t n = (size_t)M * P * P;
+    hipLaunchKernelGGL(heads_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, bias_pred, bias_weight,
+                       out_a, out_c, M, P, confidence);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// The heads' weights w [2 heads][9 taps][32 channels] (fp32, host or device memory readable by the host — 2.3 KB, packed once per checkpoint) in the
+// fragment order of conv3x3_up2_g1_kernel<HEADS>: dst 4 x 64 x 8 halfs = [hi kc0 | hi kc1 | lo kc0 | lo kc1][lane = row + 32 kgroup][8], row r of the
+// matrix product = (register group g = r >> 3, lane half hh = (r >> 2) & 1, dx = (r & 3) - 1): (dy, head) pair g + 3 hh; element e of k chunk kc, k group h
+// = channel 16 kc + 8 (e >> 2) + 4 h + (e & 3) (the order in which a lane's accumulator quads hold the convolution's output channels).
+extern "C" int omni_heads_pack_f16x3(const float* w_host, void* dst_host)
+{
+    if (!w_host || !dst_host) OMNI_FAIL(OMNI_ERR_INVALID, "omni_heads_pack: null pointer");
+    _Float16* o = (_Float16*)dst_host;
+    for (int kc = 0; kc < 2; ++kc)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const int r = lane & 31, h = lane >> 5, g = r >> 3, hh = (r >> 2) & 1, dxi = r & 3;
+                float w = 0.0f;
+                if (g < 3 && dxi < 3) {
+                    const int pair = g + 3 * hh, dy = pair / 2, head = pair % 2, ch = 16 * kc + 8 * (e >> 2) + 4 * h + (e & 3);
+                    w = w_host[(head * 9 + dy * 3 + dxi) * 32 + ch];
+                }
+                const _Float16 hi = (w < 6.103515625e-05f && w > -6.103515625e-05f) ? (_Float16)0.0f : (_Float16)w;
+                o[(kc * 64 + lane) * 8 + e] = hi;
+                o[((2 + kc) * 64 + lane) * 8 + e] = (_Float16)((w - (float)hi) * 2048.0f);
+            }
     return OMNI_OK;
 }
 

@@ -128,6 +128,11 @@ class Engine:
         W["enc_norm.w"] = f(sd["transformer.encoder_norm.weight"]); W["enc_norm.b"] = f(sd["transformer.encoder_norm.bias"])
         hw = torch.stack([sd["pred.weight"][0, :, :, :, 0], sd["weight_pred.weight"][0, :, :, :, 0]])    # [2,32,3,3]
         W["heads.w"] = f(hw.permute(0, 2, 3, 1).reshape(2, 9, 32))
+        import numpy as np                                                       # the same weights as the f16x3 operand of the fused de_conv4_0 + heads kernel
+        hw_host = np.ascontiguousarray(hw.permute(0, 2, 3, 1).reshape(2, 9, 32).to(torch.float32).numpy())
+        frag = np.zeros(4 * 64 * 8, np.float16)
+        _lib.check(_lib.load().omni_heads_pack_f16x3(hw_host.ctypes.data_as(ctypes.c_void_p), frag.ctypes.data_as(ctypes.c_void_p)), "heads_pack")
+        W["heads.w16f"] = torch.from_numpy(frag).to(dev)
         self.head_bias = (float(sd["pred.bias"][0]), float(sd["weight_pred.bias"][0]))
 
         def mlp(name):
@@ -422,16 +427,28 @@ class Engine:
         # the two widest stages, optionally a few panoramas at a time (Engine.tail_chunk; no operator here mixes patches)
         a, c = out if out is not None else (new(bs, N, 1, P, P), new(bs, N, 1, P, P) if confidence else None)
         av, cv = a.view(M, P, P), c.view(M, P, P) if c is not None else None
-        x_in, de4 = x, new(M, P, P, 32)
+        fused = sh and self.fuse_up and self.fuse_heads and P % 32 == 0
+        x_in, de4 = x, (None if fused else new(M, P, P, 32))
         for m0, m1 in self._chunks(bs, N, self.tail_chunk):
             Mc = m1 - m0
             x = self._up_conv(x_in[m0:m1], "de_conv3_0", Mc, P4, P4, 64, 64, ACT_RELU)
             x = self._conv(x, "de_conv3_1", Mc, P2, P2, 64, 32, 3, 1, 1, ACT_RELU, x2=conv1[m0:m1], C2=64)
+            if fused:                                                # de_conv4_0 + pred / weight_pred in one pass: its 302-MB output (8 panoramas) never exists
+                nb = int(lib.omni_up2_heads_scratch_bytes(Mc, P))
+                hs = new((nb + 3) // 4)
+                _lib.check(lib.omni_conv3x3_up2_heads_sh_f16x3(_p(x), _p(self.w["de_conv4_0.w16"]), _p(self.w["de_conv4_0.b"]), _p(self.w["heads.w16f"]),
+                                                               ctypes.c_float(self.head_bias[0]), ctypes.c_float(self.head_bias[1]), _p(hs), ctypes.c_size_t(nb),
+                                                               _p(av[m0:m1]), _p(cv[m0:m1]) if cv is not None else None, Mc, P, 1 if confidence else 0, self._s), "up+conv+heads")
+                continue
             self._up_conv(x, "de_conv4_0", Mc, P2, P2, 32, 32, ACT_RELU, out_f32=True, out=de4[m0:m1])
             _lib.check(lib.omni_heads_f32(_p(de4[m0:m1]), _p(self.w["heads.w"]), ctypes.c_float(self.head_bias[0]), ctypes.c_float(self.head_bias[1]),
                                           _p(av[m0:m1]), _p(cv[m0:m1]) if cv is not None else None, Mc, P, 1 if confidence else 0, self._s), "heads")
         self.last = {"de_conv4_0": de4, "layer4": layer4}
         return a, c
+
+    # de_conv4_0 and the two heads in one pass (omni_conv3x3_up2_heads_sh_f16x3): the decoder's last feature map is never written.  False: the two
+    # kernels (fp32 heads; `Engine.last["de_conv4_0"]` then holds that map — the G6 check-point test reads it).  The outputs agree to ~1e-6 relative.
+    fuse_heads = os.environ.get("OMNI_FUSE_HEADS", "1") != "0"
 
     # Passes of a few panoramas through the widest stages (same kernels, same bits) were worth +1.3 % with three forwards in flight while the
     # up-sampled tensors still went through HBM; since the up-sampling is computed inside the convolution (fuse_up) they change nothing

@@ -100,6 +100,63 @@ def test_fused_upsample_conv_equals_the_two_kernels(cfg):
     assert lib.omni_conv3x3_up2_sh_f16x3(_p(XS), _p(W16), _p(B), _p(one), 0, M, Hl, 8, C, Cout, act, _stream()) == 3      # 16 columns: OMNI_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("cfg", [(3, 64, True), (18, 128, True), (2, 32, False), (5, 96, True)])
+def test_fused_up_conv_heads_vs_the_two_kernels_and_torch(cfg):
+    """omni_conv3x3_up2_heads_sh_f16x3 — de_conv4_0 (F.interpolate + ConvBnReLU 32 -> 32) and the pred / weight_pred heads (3x3, 32 -> 1, ReLU / sigmoid, product;
+    model/spherical_model.py:300-307) in ONE pass, the 32-channel map never written — against omni_conv3x3_up2_sh_f16x3 + omni_heads_f32 and against
+    float64 torch; every tile border (4-row x 32-column tiles: neighbour sums), image border (zero padding) and patch border is inside these sizes.
+    Deterministic: two runs give the same bits."""
+    L, lib = _lib()
+    M, P, conf = cfg
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    g = torch.Generator().manual_seed(13)
+    Pl = P // 2
+    x = torch.randn(M, Pl, Pl, 32, generator=g); w = torch.randn(32, 32, 3, 3, generator=g) / np.sqrt(9 * 32); b = torch.randn(32, generator=g) * 0.3
+    hw = torch.randn(2, 32, 3, 3, generator=g) / np.sqrt(9 * 32) * 2.0; hb = (0.3, -0.2)
+    X, B = x.to(DEV), b.to(DEV)
+    W16 = split_weights_f16x3(w.permute(0, 2, 3, 1).reshape(32, -1).contiguous()).to(DEV)
+    XS = torch.empty_like(X)
+    assert lib.omni_sh_from_f32(_p(X), _p(XS), ctypes.c_size_t(X.numel()), _stream()) == 0
+    hw_nhwc = np.ascontiguousarray(hw.permute(0, 2, 3, 1).reshape(2, 9, 32).numpy())
+    frag = np.zeros(4 * 64 * 8, np.float16)
+    assert lib.omni_heads_pack_f16x3(hw_nhwc.ctypes.data_as(ctypes.c_void_p), frag.ctypes.data_as(ctypes.c_void_p)) == 0
+    HF = torch.from_numpy(frag).to(DEV)
+    # the two kernels
+    de4 = torch.empty((M, P, P, 32), device=DEV)
+    assert lib.omni_conv3x3_up2_sh_f16x3(_p(XS), _p(W16), _p(B), _p(de4), 0, M, Pl, Pl, 32, 32, 1, _stream()) == 0, lib.omni_last_error()
+    a2, c2 = torch.empty((M, P, P), device=DEV), torch.empty((M, P, P), device=DEV)
+    assert lib.omni_heads_f32(_p(de4), _p(torch.from_numpy(hw_nhwc).to(DEV)), ctypes.c_float(hb[0]), ctypes.c_float(hb[1]), _p(a2), _p(c2), M, P, 1 if conf else 0, _stream()) == 0
+    # fused
+    nb = int(lib.omni_up2_heads_scratch_bytes(M, P))
+    assert nb == M * (P // 4) * (P // 32) * 4 * 6 * 34 * 4
+    outs = []
+    for rep in range(2):
+        scratch = torch.full((nb // 4,), float("nan"), device=DEV)
+        a1, c1 = torch.full((M, P, P), float("nan"), device=DEV), torch.full((M, P, P), float("nan"), device=DEV)
+        rc = lib.omni_conv3x3_up2_heads_sh_f16x3(_p(XS), _p(W16), _p(B), _p(HF), ctypes.c_float(hb[0]), ctypes.c_float(hb[1]), _p(scratch), ctypes.c_size_t(nb),
+                                                 _p(a1), _p(c1), M, P, 1 if conf else 0, _stream())
+        assert rc == 0, lib.omni_last_error()
+        outs.append((a1, c1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    a1, c1 = outs[0]
+    assert (a1 - a2).abs().max().item() <= 2e-5 and (c1 - c2).abs().max().item() <= 2e-5, ((a1 - a2).abs().max().item(), (c1 - c2).abs().max().item())
+    # float64 torch on the SH-rounded input
+    xs_back = torch.empty_like(X)
+    assert lib.omni_sh_to_f32(_p(XS), _p(xs_back), ctypes.c_size_t(X.numel()), _stream()) == 0
+    y = F.relu(F.conv2d(F.interpolate(xs_back.cpu().double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False), w.double(), b.double(), padding=1))
+    hd = F.conv2d(y, hw.double(), torch.tensor(hb, dtype=torch.float64), padding=1)
+    pr, cf = F.relu(hd[:, 0]), torch.sigmoid(hd[:, 1])
+    assert (a1.cpu().double() - (pr * cf if conf else pr)).abs().max().item() < 3e-5
+    assert (c1.cpu().double() - cf).abs().max().item() < 3e-5
+    # out_c may be absent; a too small scratch is refused
+    a3 = torch.empty_like(a1)
+    assert lib.omni_conv3x3_up2_heads_sh_f16x3(_p(XS), _p(W16), _p(B), _p(HF), ctypes.c_float(hb[0]), ctypes.c_float(hb[1]), _p(scratch), ctypes.c_size_t(nb),
+                                               _p(a3), None, M, P, 1 if conf else 0, _stream()) == 0
+    assert torch.equal(a3, a1)
+    assert lib.omni_conv3x3_up2_heads_sh_f16x3(_p(XS), _p(W16), _p(B), _p(HF), ctypes.c_float(hb[0]), ctypes.c_float(hb[1]), _p(scratch), ctypes.c_size_t(nb - 4),
+                                               _p(a3), None, M, P, 1 if conf else 0, _stream()) != 0
+
+
 @pytest.mark.parametrize("cfg", [(6, 32, 32, 64, 64, 3), (4, 16, 16, 128, 128, 4), (2, 8, 8, 64, 64, 2)])
 def test_conv_with_post_activation_addend(cfg):
     """omni_conv2d_sh_f16x3_post_ws: relu(conv + bias + res) + post[row % rows_of_post] (layer1 + point_feat folded into the epilogue)
@@ -370,9 +427,18 @@ def test_single_pass_model_golden():
     assert out.shape == (2, 1, 64, 128) and out.dtype == torch.float32
     d = np.abs(out.cpu().numpy() - g["depth_conf"]).max()
     assert d <= 1e-3, f"confidence=True: max |d| = {d}"
-    # intermediate check-points: last decoder feature map (sub-sampled)
-    x = net._eng.last["de_conv4_0"].reshape(2, 18, 128, 128, 32).permute(0, 4, 2, 3, 1)[:, :, ::8, ::8, :]
+    # intermediate check-points: last decoder feature map (sub-sampled) — it exists only with the heads as a kernel of their own
+    from omnifusion_amd.model._engine import Engine
+    assert net._eng.last["de_conv4_0"] is None and Engine.fuse_heads
+    try:
+        Engine.fuse_heads = False
+        out_unfused = net(rgb, confidence=True)
+        x = net._eng.last["de_conv4_0"].reshape(2, 18, 128, 128, 32).permute(0, 4, 2, 3, 1)[:, :, ::8, ::8, :]
+    finally:
+        Engine.fuse_heads = True
     assert np.abs(x.cpu().numpy() - g["de_conv4_0_sub"]).max() <= 1e-3
+    assert (out_unfused - out).abs().max().item() <= 2e-5                    # fused heads: the same numbers up to summation order / f16x3 products
+    assert np.abs(out_unfused.cpu().numpy() - g["depth_conf"]).max() <= 1e-3
     out2 = net(rgb, confidence=False)
     d = np.abs(out2.cpu().numpy() - g["depth_noconf"]).max()
     assert d <= 1e-3, f"confidence=False: max |d| = {d}"
@@ -902,14 +968,20 @@ def test_library_kernel_choices_are_result_neutral():
     net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
     net.load_state_dict(make_state_dict(42, 18, False))
     rgb = torch.rand((4, 3, 64, 128), generator=torch.Generator().manual_seed(5)).to(DEV)
-    ref = net(rgb, confidence=True).clone()
-    for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1)):
+    from omnifusion_amd.model._engine import Engine
+    for fuse_heads in (True, False):                                          # (conv_up2_persist selects de_conv4_0's kernel only when the heads are a kernel of their own)
         try:
-            L.set_option(name, value)
-            out = net(rgb, confidence=True)
-            assert torch.equal(out, ref), name
+            Engine.fuse_heads = fuse_heads
+            ref = net(rgb, confidence=True).clone()
+            for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1)):
+                try:
+                    L.set_option(name, value)
+                    out = net(rgb, confidence=True)
+                    assert torch.equal(out, ref), (name, fuse_heads)
+                finally:
+                    L.set_option(name, default)
         finally:
-            L.set_option(name, default)
+            Engine.fuse_heads = True
 
 
 def test_pipelined_forwards_give_the_bits_of_plain_calls():

@@ -896,8 +896,9 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 // are its two k chunks: no data movement), three f16x3 terms like every other product = 6 matrix instructions per wave and tile beside the 54 of
 // the convolution.  The three dx terms of a row are summed across neighbouring lanes (fixed order dx = -1, 0, +1), which leaves per tile row and
 // (dy, head) 34 partial sums — pixels -1 .. 32: the two outer ones belong to the neighbouring tiles' pixels — written to `hr`
-// [tile][row 4][(dy, head) 6][34]: 3.3 KB per tile instead of 16 KB.  heads_finish_kernel adds the three rows (dy) and the neighbour tiles'
+// [tile][row 4][(dy, head) 6][32 sums | pixel -1 | pixel 32 | 2 pad]: 3.4 KB per tile instead of 16 KB.  heads_finish_kernel adds the three rows (dy) and the neighbour tiles'
 // outer sums in a fixed order, then bias, ReLU / sigmoid and the product.  Deterministic; equal to heads_kernel up to fp32 summation order.
+constexpr int HR_PITCH = 36;                                 // floats per (tile row, (dy, head)) record of `hr`: 32 sums, pixel -1, pixel 32, 2 of padding (16-byte rows)
 struct HeadsArgs { const void* w16; float* hr; };           // w16: the heads' weights in fragment order (Engine: heads.w16f), [hi kc0, hi kc1, lo kc0, lo kc1][64 lanes] x 16 B
 
 template <bool HEADS>
@@ -1017,7 +1018,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                 }
                 // rows (reg & 3) + 8 (reg >> 2) + 4 h: register group g = 0..2 is (dy, head) pair g + 3h, its registers 0..2 are dx = -1, 0, +1
                 const int px = lane & 31, h = lane >> 5;
-                float* hp = hd.hr + ((size_t)tile * TH + wave) * (6 * 34);
+                float* hp = hd.hr + ((size_t)tile * TH + wave) * (6 * HR_PITCH);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const float tl = fmaf(d1[4 * g], 4.8828125e-4f, d0[4 * g]), tc = fmaf(d1[4 * g + 1], 4.8828125e-4f, d0[4 * g + 1]),
@@ -1025,9 +1026,9 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                     // out[q] takes w[dx] . x[q + dx]: its dx = -1 term comes from pixel q - 1, its dx = +1 term from pixel q + 1
                     const float fl = __shfl_up(tl, 1, 32), fr = __shfl_down(tr, 1, 32);
                     const float sum = ((px > 0 ? fl : 0.0f) + tc) + (px < 31 ? fr : 0.0f);
-                    float* row = hp + (g + 3 * h) * 34;
-                    row[1 + px] = sum;
-                    if (px == 0) row[0] = tr;                      // pixel -1 of this row (the left neighbour tile's column 31) takes my dx = +1 term
+                    float* row = hp + (g + 3 * h) * HR_PITCH;
+                    row[px] = sum;
+                    if (px == 0) row[32] = tr;                     // pixel -1 of this row (the left neighbour tile's column 31) takes my dx = +1 term
                     if (px == 31) row[33] = tl;                    // pixel 32 takes my dx = -1 term
                 }
             } else
@@ -1383,32 +1384,38 @@ __global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restr
 
 // Second half of the fused heads (see conv3x3_up2_g1_kernel<HEADS>): one thread per output pixel adds, for each head, the partial sums of the three
 // source rows (dy = -1, 0, +1: row y + dy of its tile, (dy, head) plane, position 1 + x % 32) and, at a tile's first / last column, the outer sums
-// of the horizontally neighbouring tile (positions 33 / 0) — in that fixed order — then heads_kernel's own tail (bias, ReLU, sigmoid, product).
+// of the horizontally neighbouring tile (its pixel 32 / pixel -1 slots) — in that fixed order — then heads_kernel's own tail (bias, ReLU, sigmoid, product).
 __global__ __launch_bounds__(256) void heads_finish_kernel(const float* __restrict__ hr, float bp, float bw, float* __restrict__ outa, float* __restrict__ outc,
                                                            int M, int P, int conf)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * P * P) return;
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;  // four consecutive pixels of a row per thread (16-byte loads and stores)
+    if (i4 >= (size_t)M * P * P / 4) return;
+    const size_t i = i4 * 4;
     const int x = (int)(i % P), y = (int)((i / P) % P), m = (int)(i / ((size_t)P * P));
     const int tw = P / HT_W, th = P / 4, c = x & 31;
-    float s[2] = {0.0f, 0.0f};
+    f4v s[2] = {(f4v)(0.0f), (f4v)(0.0f)};
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
         const int py = y + dy;
         if ((unsigned)py >= (unsigned)P) continue;
         const size_t tile = ((size_t)m * th + (py >> 2)) * tw + (x >> 5);
-        const float* rowp = hr + (tile * 4 + (py & 3)) * (6 * 34) + (dy + 1) * 2 * 34;
+        const float* rowp = hr + (tile * 4 + (py & 3)) * (6 * HR_PITCH) + (dy + 1) * 2 * HR_PITCH;
 #pragma unroll
         for (int hd = 0; hd < 2; ++hd) {
-            s[hd] += rowp[hd * 34 + 1 + c];
-            if (c == 0 && x > 0) s[hd] += rowp[hd * 34 + 33 - 4 * 6 * 34];          // the left neighbour tile's pixel 32
-            if (c == 31 && x + 1 < P) s[hd] += rowp[hd * 34 + 4 * 6 * 34];          // the right neighbour tile's pixel -1
+            s[hd] += *reinterpret_cast<const f4v*>(rowp + hd * HR_PITCH + c);
+            if (c == 0 && x > 0) s[hd].x += rowp[hd * HR_PITCH + 33 - 4 * 6 * HR_PITCH];        // the left neighbour tile's pixel 32
+            if (c == 28 && x + 4 < P) s[hd].w += rowp[hd * HR_PITCH + 32 + 4 * 6 * HR_PITCH];   // the right neighbour tile's pixel -1
         }
     }
-    const float ap = s[0] + bp, aw = s[1] + bw;
-    const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
-    outa[i] = conf ? pr * cf : pr;
-    if (outc) outc[i] = cf;
+    f4v oa, oc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ap = s[0][e] + bp, aw = s[1][e] + bw;
+        const float pr = fmaxf(ap, 0.0f), cf = 1.0f / (1.0f + expf(-aw));
+        oa[e] = conf ? pr * cf : pr; oc[e] = cf;
+    }
+    *reinterpret_cast<f4v*>(outa + i) = oa;
+    if (outc) *reinterpret_cast<f4v*>(outc + i) = oc;
 }
 
 // dst = act(sum_s ws[s] + bias + res): the deterministic second pass of a split-K launch (4 channels per thread)
@@ -1869,7 +1876,7 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
 extern "C" size_t omni_up2_heads_scratch_bytes(int M, int P)
 {
     if (M <= 0 || P <= 0 || P % 32) return 0;
-    return (size_t)M * (P / 4) * (P / 32) * 4 * 6 * 34 * sizeof(float);
+    return (size_t)M * (P / 4) * (P / 32) * 4 * 6 * HR_PITCH * sizeof(float);
 }
 extern "C" int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16, const float* bias, const void* heads_w16f, float bias_pred, float bias_weight,
                                                float* scratch, size_t scratch_bytes, float* out_a, float* out_c, int M, int P, int confidence, omni_stream_t stream)
@@ -1886,7 +1893,7 @@ extern "C" int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16
     const int grid = M * (P / 4) * (P / HT_W);
     hipLaunchKernelGGL(conv3x3_up2_g1_kernel<true>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid, HeadsArgs{heads_w16f, scratch});
     OMNI_HIP(hipGetLastError());
-    const size_t n = (size_t)M * P * P;
+    const size_t n = (size_t)M * P * P / 4;
     hipLaunchKernelGGL(heads_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, bias_pred, bias_weight,
                        out_a, out_c, M, P, confidence);
     OMNI_HIP(hipGetLastError());

@@ -164,7 +164,8 @@ class Engine:
         flag, viol = ctypes.c_int(0), ctypes.c_int(0)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().omni_sh_overflow(ctypes.byref(flag), 1 if reset else 0), "sh_overflow")
-            _lib.check(_lib.load().omni_conv_sk_status(ctypes.byref(viol), 1 if reset else 0), "conv_sk_status")
+            if self.in_launch_reduce:                             # (experimental path only: its premise is checked by every block)
+                _lib.check(_lib.load().omni_conv_sk_status(ctypes.byref(viol), 1 if reset else 0), "conv_sk_status")
         if viol.value:
             raise RuntimeError("a convolution block ran on another XCD than its block id implies: the in-launch split-K reduction hands partial tiles over "
                                "through ONE XCD's L2 and its results may be wrong on this device / partition mode — rerun with OMNI_CONV_SK=0")
@@ -427,7 +428,7 @@ class Engine:
         # the two widest stages, optionally a few panoramas at a time (Engine.tail_chunk; no operator here mixes patches)
         a, c = out if out is not None else (new(bs, N, 1, P, P), new(bs, N, 1, P, P) if confidence else None)
         av, cv = a.view(M, P, P), c.view(M, P, P) if c is not None else None
-        fused = sh and self.fuse_up and self.fuse_heads and P % 32 == 0
+        fused = sh and self.fuse_heads and P % 32 == 0              # (the fused kernel up-samples inside whatever `fuse_up` says)
         x_in, de4 = x, (None if fused else new(M, P, P, 32))
         for m0, m1 in self._chunks(bs, N, self.tail_chunk):
             Mc = m1 - m0

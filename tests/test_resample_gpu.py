@@ -49,6 +49,11 @@ P2E_FLIPS = {
 # Samples at which equi2pers misses the reference (goldens) / the oracle by more than 1e-3 on i.i.d. inputs (a bilinear tap one pixel off where
 # the sampling coordinate sits within round-off of an integer: polar longitudes).  Counts measured on MI355X in round 5, pinned like P2E_FLIPS.
 E2P_OUTLIERS = {
+    "G1_equi2pers_n4": 0, "G2_equi2pers_n6": 0, "G2b_equi2pers_n3": 0, "G2b_equi2pers_n5": 0, "G2c_equi2pers_rect": 0,
+    "G8_config1": 0, "G8_config3": 5,                                       # of 55 296 / 47 104 sub-sampled values
+    (2, 3, 512, 1024, 4, 256): 86, (1, 3, 1024, 2048, 6, 256): 109, (1, 1, 256, 512, 5, 64): 0, (1, 2, 200, 333, 3, 50): 0,      # of 7.08 M / 9.04 M / ...
+    ("planar", 8, 512, 1024, 4, 256): 360, ("planar", 8, 512, 1024, 4, 128): 24,                                         # of 28.3 M / 7.08 M
+    ("cfg5", "float32"): 16, ("cfg5", "float16"): 2,                                                                      # of 12.06 M (tol 1e-3 / 4e-3)
 }
 
 

@@ -200,6 +200,22 @@ int omni_gemm_rows_ln_sh_f16x3(const float* x, const float* ln_weight, const flo
  * 2Wl % 32 == 0 and 2Hl % 4 == 0 (else OMNI_ERR_UNSUPPORTED: omni_upsample_bilinear_sh + omni_conv2d_sh_f16x3_ws give the same bits). */
 int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, const float* bias, void* dst, int fmt,
                               int M, int Hl, int Wl, int C, int Cout, int act, omni_stream_t stream);
+/* Transformer_cascade (model/spherical_model.py:169-187, model/blocks.py:14-89) of a small batch in ONE cooperative launch: 6 x [LN1 + qkv | attention |
+ * proj + residual | LN2 + fc1 + GELU | fc2 + residual] + encoder_norm, device-wide barriers between the phases, every block's next weights in flight
+ * while it waits.  A layer record holds DEVICE pointers: LayerNorm weights / biases and the proj / fc1 / fc2 biases fp32; the four matrices in the fragment
+ * order of omni_gemm_rows_pack — qkv = cat(attn.q.weight, attn.kv.weight) [1536,512], proj [512,512], fc1 [2048,512], fc2 [512,2048].  tok fp32 [B*N,512]
+ * (token + pos_emb; overwritten), out fp32 [B*N,512] = encoder_norm of the result; scratch omni_transformer_scratch_bytes(B*N) bytes; sync: TWO zero-
+ * initialised 32-bit counters per execution context (stream), left zero.  N <= 64, B*N <= 4096.  Element for element the arithmetic of
+ * omni_gemm_rows_ln_sh_f16x3 / omni_attention_qkv_sh / omni_gemm_rows_sh_f16x3 / omni_layernorm512_f32 (same bits), for every panorama of the batch. */
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *proj_b, *fc1_b, *fc2_b;
+    const void *qkv_w16r, *proj_w16r, *fc1_w16r, *fc2_w16r;
+} omni_xf_layer;
+size_t omni_transformer_scratch_bytes(int M);
+int omni_transformer_sh_f16x3(float* tok, const omni_xf_layer* layers, const float* enc_w, const float* enc_b, float* out,
+                              void* scratch, size_t scratch_bytes, unsigned* sync, int B, int N, omni_stream_t stream);
+/* *timeouts = 1 if a block of omni_transformer_sh_f16x3 ever gave up waiting at a device-wide barrier (grid not co-resident for ~1 s).  Synchronises. */
+int omni_transformer_status(int* timeouts, int reset);
 /* de_conv4_0 AND the two heads in one pass over the widest tensor of the network (model/spherical_model.py:300-307: F.interpolate + ConvBnReLU 32 -> 32,
  * then pred (ReLU) / weight_pred (sigmoid), 3x3, 32 -> 1, and their product): a = relu(pred(y)) * (confidence ? sigmoid(weight_pred(y)) : 1),
  * c = sigmoid(weight_pred(y)); y = de_conv4_0's output never exists.  src SH [M,P/2,P/2,32]; heads_w16f from omni_heads_pack_f16x3; scratch of

@@ -1985,13 +1985,14 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
 // layout conversions (n = number of elements, a multiple of 32 channels per pixel)
 OMNI_SH_OVERFLOW_ACCESSOR(omni_sh_overflow_conv)          // this translation unit's copy of the sticky range flag
 int omni_sh_overflow_net(unsigned* out, int reset);      // omni_net.hip's
+int omni_sh_overflow_xformer(unsigned* out, int reset);  // omni_xformer.hip's
 
 extern "C" int omni_sh_overflow(int* flag, int reset)
 {
     if (!flag) OMNI_FAIL(OMNI_ERR_INVALID, "omni_sh_overflow: null output");
     OMNI_HIP(hipDeviceSynchronize());                    // diagnostic entry point, never on the hot path
     unsigned v = 0;
-    if (omni_sh_overflow_conv(&v, reset) != 0 || omni_sh_overflow_net(&v, reset) != 0)
+    if (omni_sh_overflow_conv(&v, reset) != 0 || omni_sh_overflow_net(&v, reset) != 0 || omni_sh_overflow_xformer(&v, reset) != 0)
         OMNI_FAIL(OMNI_ERR_HIP, "omni_sh_overflow: could not read the device flag");
     *flag = v ? 1 : 0;
     return OMNI_OK;

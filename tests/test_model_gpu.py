@@ -740,6 +740,42 @@ def test_in_launch_splitk_reduction_equals_two_launch_form(cfg):
     print("in-launch reduction: block-on-unexpected-XCD flag =", flag.value)
 
 
+def test_cooperative_transformer_gives_the_bits_of_the_per_operator_kernels():
+    """csrc/omni_xformer.hip: Transformer_cascade (model/spherical_model.py:169-187, blocks.py:14-89) in ONE cooperative launch — device-wide barriers
+    between the phases — must reproduce the per-operator path: bit for bit for a lone panorama (whose forward runs exactly the kernels the phases are made
+    of: omni_gemm_rows_ln_sh / attention / gemm_rows), to fp32 summation order for a batch (whose per-operator path uses the tile kernels), for 18 and 46
+    tokens, also with several such grids in flight (pipelined forwards), and never time out at a barrier."""
+    from omnifusion_amd.model._engine import Engine
+    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
+    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
+    net.load_state_dict(make_state_dict(42, 18, False))
+    rgb = torch.rand((5, 3, 64, 128), generator=torch.Generator().manual_seed(3)).to(DEV)
+    net6 = spherical_fusion_it(6, 46, (128, 128), (80, 80)).cuda()
+    net6.load_state_dict(make_state_dict(42, 46, True))
+    rgb6 = torch.rand((2, 3, 64, 128), generator=torch.Generator().manual_seed(4)).to(DEV)
+    assert Engine.coop_transformer
+    try:
+        Engine.coop_transformer = False
+        ref1, ref5 = net(rgb[:1]).clone(), net(rgb).clone()
+        ref6 = [o.clone() for o in net6(rgb6[:1], iter=2)]
+        ref6b = [o.clone() for o in net6(rgb6, iter=2)]
+    finally:
+        Engine.coop_transformer = True
+    for rep in range(3):
+        assert torch.equal(net(rgb[:1]), ref1)                               # a lone panorama: the same kernels' arithmetic, the same bits
+        out5 = net(rgb)
+        assert (out5 - ref5).abs().max().item() <= 2e-5
+        assert torch.equal(net(rgb[1:4]), out5[1:4])                          # ... and a panorama's bits do not depend on its batch
+    o6 = net6(rgb6[:1], iter=2)
+    assert all(torch.equal(a, b) for a, b in zip(o6, ref6))                   # 46 tokens = two row tiles, two iterations
+    o6b = net6(rgb6, iter=2)
+    assert max((a - b).abs().max().item() for a, b in zip(o6b, ref6b)) <= 2e-5
+    run = net.pipelined(3)                                                    # three cooperative grids in flight
+    pend = [run(rgb) for _ in range(9)]
+    assert all(torch.equal(p.get(), out5) for p in pend)
+    assert not net.overflowed() and not net6.overflowed()                     # (raises if a barrier ever timed out)
+
+
 def test_dataparallel_over_several_replicas_in_one_process():
     """test.py:105-111 on a multi-GPU node: `nn.DataParallel(network)` scatters the batch over replica THREADS.  device_ids=[0, 0]
     drives exactly that code path on one GPU (scatter -> replicate -> parallel_apply on two threads -> gather): the replicas run on

@@ -45,15 +45,17 @@ struct XfArgs {
     unsigned char* hid;                                              // [M, 2048] SH scratch
     float* out;                                                      // [M, 512] fp32: encoder_norm(tok)
     unsigned* sync;                                                  // [0] arrivals, [1] exits: zero between launches
+    long long* trace;                                                // tools only (omni_debug_set_trace): wall_clock64 of block 0 before / after every barrier
     int M, N, B;
 };
 
 __device__ unsigned xf_timeout_flag = 0;
 
 // device-wide barrier number k (1-based) of this launch: everything this block wrote is visible to every block that leaves it
-__device__ __forceinline__ void xf_barrier(unsigned* sync, unsigned k)
+__device__ __forceinline__ void xf_barrier(unsigned* sync, unsigned k, long long* trace)
 {
     __syncthreads();
+    if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[2 * k - 1] = wall_clock64();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // (release: this XCD's dirty lines are written back first)
         const unsigned target = k * (unsigned)XF_GRID;
@@ -63,6 +65,7 @@ __device__ __forceinline__ void xf_barrier(unsigned* sync, unsigned k)
             if (++spins > XF_SPIN_LIMIT) { atomicOr(&xf_timeout_flag, 1u); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire: stale lines of this CU's L1 / this XCD's L2 are dropped
+        if (trace && blockIdx.x == 0) trace[2 * k] = wall_clock64();
     }
     __syncthreads();
 }
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(XF_THREADS) void transformer_coop_kernel(XfArgs a)
     const int t_fc1 = blk;
     const int t_fc2 = (blk & 3) == 2 ? blk >> 2 : -1;            // (other blocks than the proj tiles: their weights travel during the fc1 phase)
     unsigned bar = 0;
+    if (a.trace && blk == 0 && t == 0) a.trace[0] = wall_clock64();
 
     h8v Wa[2][4], Wb[8][4];
     if (t_qkv >= 0) xf_load_w<2>(a.L[0].wqkv, t_qkv, 16, wave, lane, Wa);
@@ -229,16 +233,16 @@ __global__ __launch_bounds__(XF_THREADS) void transformer_coop_kernel(XfArgs a)
                 xf_gemm_tile<2, XF_EPI_QKV>(Wa, xs, 16, min(32, M - rt * 32), rt * 32, t_qkv, 1536, nullptr, nullptr, a.qkv, red, wave, lane);
             }
         if (t_proj >= 0) xf_load_w<2>(L.wproj, t_proj, 16, wave, lane, Wa);          // travels across the next two barriers
-        xf_barrier(a.sync, ++bar);
+        xf_barrier(a.sync, ++bar, a.trace);
         // ---- attention: (panorama, head) pairs over the blocks
         for (int u = blk; u < a.B * 4; u += XF_GRID) xf_attention(a.qkv, a.att, u >> 2, u & 3, a.N, smem, wave, lane);
-        xf_barrier(a.sync, ++bar);
+        xf_barrier(a.sync, ++bar, a.trace);
         // ---- proj + bias + residual
         if (t_proj >= 0)
             for (int rt = 0; rt < rtiles; ++rt)
                 xf_gemm_tile<2, XF_EPI_RES>(Wa, a.att + (size_t)rt * 32 * 2048, 16, min(32, M - rt * 32), rt * 32, t_proj, 512, L.bproj, a.tok, a.tok, red, wave, lane);
         xf_load_w<2>(L.wfc1, t_fc1, 16, wave, lane, Wa);
-        xf_barrier(a.sync, ++bar);
+        xf_barrier(a.sync, ++bar, a.trace);
         // ---- LN2 + fc1 + bias + GELU -> split-half hidden rows
         for (int rt = 0; rt < rtiles; ++rt) {
             xf_ln_tile(a.tok, L.ln2g, L.ln2b, 1e-5f, rt * 32, M, xs, wave, lane);
@@ -246,13 +250,13 @@ __global__ __launch_bounds__(XF_THREADS) void transformer_coop_kernel(XfArgs a)
             xf_gemm_tile<2, XF_EPI_GELU_SH>(Wa, xs, 16, min(32, M - rt * 32), rt * 32, t_fc1, 2048, L.bfc1, nullptr, a.hid, red, wave, lane);
         }
         if (t_fc2 >= 0) xf_load_w<8>(L.wfc2, t_fc2, 64, wave, lane, Wb);
-        xf_barrier(a.sync, ++bar);
+        xf_barrier(a.sync, ++bar, a.trace);
         // ---- fc2 + bias + residual
         if (t_fc2 >= 0)
             for (int rt = 0; rt < rtiles; ++rt)
                 xf_gemm_tile<8, XF_EPI_RES>(Wb, a.hid + (size_t)rt * 32 * 8192, 64, min(32, M - rt * 32), rt * 32, t_fc2, 512, L.bfc2, a.tok, a.tok, red, wave, lane);
         if (l + 1 < XF_LAYERS && t_qkv >= 0) xf_load_w<2>(a.L[l + 1].wqkv, t_qkv, 16, wave, lane, Wa);
-        xf_barrier(a.sync, ++bar);
+        xf_barrier(a.sync, ++bar, a.trace);
     }
     // ---- encoder_norm (eps 1e-6), a row per wave: layernorm512_kernel<false>
     for (int row = blk * XF_NW + wave; row < M; row += XF_GRID * XF_NW) {
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(XF_THREADS) void transformer_coop_kernel(XfArgs a)
         act_store4<false>(a.out, (size_t)row * 512 + lane * 4, v0 * rstd * g0 + b0);
         act_store4<false>(a.out, (size_t)row * 512 + 256 + lane * 4, v1 * rstd * g1 + b1);
     }
+    if (a.trace && blk == 0 && t == 0) a.trace[2 * bar + 1] = wall_clock64();
     // ---- the counters are clean for the next launch: the last block to leave (every block has passed the last barrier by then) resets them
     __syncthreads();
     if (t == 0) {
@@ -314,6 +319,11 @@ extern "C" int omni_transformer_sh_f16x3(float* tok, const omni_xf_layer* layers
             OMNI_FAIL(OMNI_ERR_INVALID, "omni_transformer_sh: null pointer in a layer record");
         memcpy(&a.L[l], &s, sizeof(XfLayer));
     }
+#ifdef OMNI_DEBUG_BUILD
+    a.trace = omni_debug_trace_buf();
+#else
+    a.trace = nullptr;
+#endif
     a.encg = enc_w; a.encb = enc_b; a.tok = tok; a.out = out; a.sync = sync; a.M = (int)M; a.N = N; a.B = B;
     a.qkv = (float*)scratch;
     a.att = (unsigned char*)scratch + (size_t)M * 1536 * 4;

@@ -466,9 +466,10 @@ class Engine:
     fuse_heads = os.environ.get("OMNI_FUSE_HEADS", "1") != "0"
 
     # Transformer_cascade as ONE cooperative launch (device-wide barriers between the phases, the next phase's weights in flight while a block waits) for
-    # batches of up to COOP_MAX_ROWS token rows; False / larger: one launch per operator.  Per row the arithmetic of the lone-panorama kernels
-    # (omni_gemm_rows_*): a panorama's bits are those of its own single-panorama forward's transformer, in any batch.
-    coop_transformer = os.environ.get("OMNI_COOP_TRANSFORMER", "1") != "0"
+    # batches of up to COOP_MAX_ROWS token rows; False (default) / larger: one launch per operator.  Per row the arithmetic of the lone-panorama kernels
+    # (omni_gemm_rows_*): a panorama's bits are those of its own single-panorama forward's transformer, in any batch.  Built for VERDICT r4 #6 and measured
+    # SLOWER than the per-operator launches (0.954 -> 1.087 ms for one panorama, 2.42 -> 2.76 ms at 8; profiles/r05b_coop_transformer.txt): off.
+    coop_transformer = os.environ.get("OMNI_COOP_TRANSFORMER", "0") != "0"
     COOP_MAX_ROWS = 256
 
     def _xf_layers(self):

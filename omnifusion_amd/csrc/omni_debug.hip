@@ -295,3 +295,52 @@ extern "C" int omni_debug_grid_barrier(int* counters, float* buf, int iters, int
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }
+
+// ------------------------------------------------------------------ FETCH_SIZE calibration (VERDICT r4 #7b; tools/fetch_calib.py under rocprofv3 --pmc FETCH_SIZE)
+// Kernels that read a KNOWN number of bytes once, in the access forms the product's kernels use: 16-byte LDS-DMA (conv / resample operand tiles), 16-byte and
+// 8-byte per-lane loads (tables), 4-byte gathers that touch one element per 128-byte line / per 64-byte half line / per 32-byte sector.  The guide calibrates
+// the counter's unit on gfx950 for 16-byte streaming only; every traffic figure under profiles/ applies the same factor to kernels that gather.
+namespace {
+typedef __attribute__((address_space(3))) void* cal_lptr_t;
+__global__ __launch_bounds__(256) void calib_dma16_kernel(const unsigned char* __restrict__ src, unsigned bytes, float* __restrict__ sink)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), (short)0, (int)bytes, 0x00020000);
+    const unsigned per_wave = 1024u, nw = gridDim.x * 4u;
+    for (unsigned o = (blockIdx.x * 4u + wave) * per_wave; o < bytes; o += nw * per_wave) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cal_lptr_t)(lds + wave * 1024), 16, (int)(o + lane * 16), 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (lds[threadIdx.x * 16] == 77 && sink[0] == -1.0f) sink[1] = 1.0f;
+}
+template <typename V>
+__global__ __launch_bounds__(256) void calib_ld_kernel(const V* __restrict__ src, size_t n, float* __restrict__ sink)
+{
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const V v = src[i]; acc += v.x; }
+    if (acc == -1.2345f) sink[0] = acc;
+}
+// one 4-byte element per `stride` bytes, every element once, lanes of a wave on CONSECUTIVE strides (the layout of a sampling-table gather)
+__global__ __launch_bounds__(256) void calib_gather4_kernel(const float* __restrict__ src, size_t n, int stride_f, float* __restrict__ sink)
+{
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += src[i * (size_t)stride_f];
+    if (acc == -1.2345f) sink[0] = acc;
+}
+}  // namespace
+// pattern 0: LDS-DMA 16 B/lane | 1: 16-byte loads | 2: 8-byte loads | 3: 4-byte loads, contiguous | 4: 4-byte gathers, one per `param` bytes (32 / 64 / 128 / 256)
+extern "C" int omni_debug_calib(int pattern, const void* src, size_t bytes, int param, float* sink, omni_stream_t stream)
+{
+    if (!src || !sink || bytes == 0 || bytes >= (1ull << 32)) OMNI_FAIL(OMNI_ERR_INVALID, "omni_debug_calib: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = omni_num_cus() * 8;
+    if (pattern == 0) hipLaunchKernelGGL(calib_dma16_kernel, dim3(grid), dim3(256), 0, s, (const unsigned char*)src, (unsigned)bytes, sink);
+    else if (pattern == 1) hipLaunchKernelGGL(calib_ld_kernel<float4>, dim3(grid), dim3(256), 0, s, (const float4*)src, bytes / 16, sink);
+    else if (pattern == 2) hipLaunchKernelGGL(calib_ld_kernel<float2>, dim3(grid), dim3(256), 0, s, (const float2*)src, bytes / 8, sink);
+    else if (pattern == 3) hipLaunchKernelGGL(calib_gather4_kernel, dim3(grid), dim3(256), 0, s, (const float*)src, bytes / 4, 1, sink);
+    else if (pattern == 4 && param >= 4 && param % 4 == 0) hipLaunchKernelGGL(calib_gather4_kernel, dim3(grid), dim3(256), 0, s, (const float*)src, bytes / param, param / 4, sink);
+    else OMNI_FAIL(OMNI_ERR_INVALID, "omni_debug_calib: unknown pattern");
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}

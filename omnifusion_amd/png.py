@@ -74,12 +74,12 @@ class PngBatches:
     k+workers runs while batch k crosses PCIe and the network) — the role of the reference's 8 DataLoader workers (test.py:90-97) for the
     decode step.  A PNG is one deflate stream: an image occupies ONE thread, so a batch of 8 keeps 8 host threads busy whatever the pool's
     size (round 5 measured 1100 panoramas/s that way against 3800 consumed): several batches are decoded side by side, delivered in order.
-    workers = 0: as many as the host's threads allow at `batch` threads each, at most 8."""
+    workers = 0: as many as the host's cores allow at `batch` threads each, at most 16."""
 
     def __init__(self, paths, batch, threads=0, pinned=True, ring=0, workers=0):
         self.paths, self.batch, self.threads, self.pinned = list(paths), int(batch), int(threads), pinned
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        self.workers = int(workers) if workers > 0 else max(1, min(8, ncpu // max(1, self.batch)))
+        self.workers = int(workers) if workers > 0 else max(1, min(16, ncpu // (2 * max(1, self.batch))))   # (two hardware threads per core: one decoder per core)
         self.ring = max(2, int(ring), self.workers + 1)            # decoded-but-unconsumed batches (= buffers in flight)
         self._pool, self._pool_lock = [], threading.Lock()         # buffers handed back by the consumer: (tensor, event or None)
 

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libomnifusion_hip.so")
+LIB_PATH = os.environ.get("OMNI_LIB_VARIANT") or os.path.join(_HERE, "csrc", "libomnifusion_hip.so")    # (OMNI_LIB_VARIANT: tools/ only — a variant build of the library for same-box A/B timings)
 LIB_PATH_DEBUG = os.path.join(_HERE, "csrc", "libomnifusion_hip_dbg.so")     # tools/ only: ablation switches + micro-benchmarks
 
 OMNI_OK, OMNI_ERR_INVALID, OMNI_ERR_HIP, OMNI_ERR_UNSUPPORTED = 0, 1, 2, 3

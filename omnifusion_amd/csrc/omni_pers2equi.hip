@@ -60,7 +60,9 @@ __device__ __forceinline__ void p2e_lon(const P2EArgs& a, int n, float slon, flo
     cd = clon * cl0 + slon * sl0;                                   // cos(lon - l0)
     sd = slon * cl0 - clon * sl0;                                   // sin(lon - l0)
 }
-__device__ __forceinline__ bool p2e_taps_core(const P2EArgs& a, float sp, float cp, float slat, float clat, float cd, float sd, Taps& t)
+// the float part of the taps (everything but the integer conversions): the four weights and the tap coordinates as floats
+struct TapsF { float x0f, x1f, y0f, y1f; float wa, wb, wc, wd; };
+__device__ __forceinline__ bool p2e_taps_f(const P2EArgs& a, float sp, float cp, float slat, float clat, float cd, float sd, TapsF& t)
 {
     const float cos_c = sp * slat + cp * clat * cd;                 // :112
     // :113-114 divide twice by cos_c; one reciprocal and two products differ from that by <= 2 ulp of X, Y (a
@@ -80,12 +82,14 @@ __device__ __forceinline__ bool p2e_taps_core(const P2EArgs& a, float sp, float 
     // taps can leave it (at the far edge); for an invalid pixel every weight is zeroed below and no kernel uses its indices.
     const float x0f = fx, x1f = fminf(fx + 1.0f, fw - 1.0f);
     const float y0f = fy, y1f = fminf(fy + 1.0f, fh - 1.0f);
-    float wa = (x1f - X) * (y1f - Y);                               // :139  tap (y0,x0)
-    float wb = (x1f - X) * (Y - y0f);                               // :140  tap (y1,x0)
-    float wc = (X - x0f) * (y1f - Y);                               // :141  tap (y0,x1)
-    float wd = (X - x0f) * (Y - y0f);                               // :142  tap (y1,x1)
-    // :144-147 multiply by mask, :191 zero everything <= 1e-5
-    wa = valid ? wa : 0.0f; wb = valid ? wb : 0.0f; wc = valid ? wc : 0.0f; wd = valid ? wd : 0.0f;
+    // :144-147 multiply by mask: the mask goes onto the two x factors (two selects instead of four; for a valid pixel the products are the
+    // reference's, for an invalid one they are 0, -0 or — where Y is not finite — NaN, and the threshold below turns all three into 0)
+    const float hx1 = valid ? x1f - X : 0.0f, hx0 = valid ? X - x0f : 0.0f;
+    const float wa = hx1 * (y1f - Y);                               // :139  tap (y0,x0)
+    const float wb = hx1 * (Y - y0f);                               // :140  tap (y1,x0)
+    const float wc = hx0 * (y1f - Y);                               // :141  tap (y0,x1)
+    const float wd = hx0 * (Y - y0f);                               // :142  tap (y1,x1)
+    // :191 zero everything <= 1e-5 (a NaN compares false)
     t.wa = wa > 1e-5f ? wa : 0.0f;
     t.wb = wb > 1e-5f ? wb : 0.0f;
     t.wc = wc > 1e-5f ? wc : 0.0f;
@@ -97,8 +101,33 @@ __device__ __forceinline__ bool p2e_taps_core(const P2EArgs& a, float sp, float 
     const bool xedge = x1f == x0f;
     t.wd = xedge ? t.wd + t.wa : t.wd;
     t.wa = xedge ? 0.0f : t.wa;
-    t.x0 = (int)x0f; t.x1 = (int)x1f; t.y0 = (int)y0f; t.y1 = (int)y1f;
+    t.x0f = x0f; t.x1f = x1f; t.y0f = y0f; t.y1f = y1f;
     return valid;
+}
+__device__ __forceinline__ bool p2e_taps_core(const P2EArgs& a, float sp, float cp, float slat, float clat, float cd, float sd, Taps& t)
+{
+    TapsF f;
+    const bool valid = p2e_taps_f(a, sp, cp, slat, clat, cd, sd, f);
+    t.wa = f.wa; t.wb = f.wb; t.wc = f.wc; t.wd = f.wd;
+    t.x0 = (int)f.x0f; t.x1 = (int)f.x1f; t.y0 = (int)f.y0f; t.y1 = (int)f.y1f;
+    return valid;
+}
+// The taps as the LDS kernels use them: element offsets of the two tap ROW pairs inside a box whose origin is (xa, ymin) and whose rows are `pitch`
+// elements apart — the pair (x1 - 1, x1) of rows y0 and y1 (at the right patch edge, x1 == x0, wa == wb == 0 and the pair's second element is the x1
+// tap: no select) — and the weights; a pixel the patch does not cover (all weights 0) reads the box origin.  Returns the weight sum.
+// (xo = x0 - (xa + 1 - (x1 - x0)) = x1 - xa - 1; y1 - y0 is 0 or 1: one 24-bit multiply-add and one select instead of two 32-bit multiplies.)
+__device__ __forceinline__ float p2e_taps_box(const P2EArgs& a, float sp, float cp, float slat, float clat, float cd, float sd, int xa1, int ymin, int pitch,
+                                              int& r0, int& r1, float& wa, float& wb, float& wc, float& wd)
+{
+    TapsF f;
+    p2e_taps_f(a, sp, cp, slat, clat, cd, sd, f);
+    const float wsum = (f.wa + f.wb) + (f.wc + f.wd);               // all >= 0 after the threshold
+    const bool used = wsum > 0.0f;
+    const int o0 = __mul24((int)f.y0f - ymin, pitch) + ((int)f.x1f - xa1);
+    r0 = used ? o0 : 0;
+    r1 = used ? o0 + (f.y1f != f.y0f ? pitch : 0) : 0;
+    wa = f.wa; wb = f.wb; wc = f.wc; wd = f.wd;
+    return wsum;
 }
 __device__ __forceinline__ bool p2e_taps_cs(const P2EArgs& a, int n, float slat, float clat, float cd, float sd, Taps& t)
 {
@@ -498,19 +527,11 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
         const float sd = ct.x * cl0 - ct.y * sl0;                   //                                                          sin(lon - l0)
 #pragma unroll
         for (int k = 0; k < NPX; ++k) {
-            Taps t;
-            if (OMNI_DBG(a, 1)) { t.x0 = xa + 1; t.x1 = xa + 2; t.y0 = ymin; t.y1 = ymin; t.wa = t.wb = t.wc = t.wd = 0.25f * rt[k].x; }
-            else p2e_taps_core(a, sp, cp, rt[k].x, rt[k].y, cd, sd, t);
-            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);           // all >= 0 after the threshold
-            l1[k] += wsum;
-            // the pair (x0, x0+1) of both tap rows; at the right patch edge (x1 == x0: wa == wb == 0, see p2e_taps_cs) the pair is
+            // the pair (x0, x0+1) of both tap rows; at the right patch edge (x1 == x0: wa == wb == 0, see p2e_taps_f) the pair is
             // moved one column left so that its SECOND element is the x1 tap.  Pixels the patch does not cover have all weights 0
-            // and read the box origin.
-            const int xo = t.x0 - xa_adj(t.x0, t.x1, xa);
-            const bool used = wsum > 0.0f;
-            r0[k] = used ? (t.y0 - ymin) * pitch + xo : 0;
-            r1[k] = used ? (t.y1 - ymin) * pitch + xo : 0;
-            wa[k] = t.wa; wb[k] = t.wb; wc[k] = t.wc; wd[k] = t.wd;
+            // and read the box origin (p2e_taps_box).
+            if (OMNI_DBG(a, 1)) { r0[k] = r1[k] = 1; wa[k] = wb[k] = wc[k] = wd[k] = 0.25f * rt[k].x; l1[k] += rt[k].x; continue; }
+            l1[k] += p2e_taps_box(a, sp, cp, rt[k].x, rt[k].y, cd, sd, xa + 1, ymin, pitch, r0[k], r1[k], wa[k], wb[k], wc[k], wd[k]);
         }
         // ---- (3) the PL stages, instantiated on the number of DMA pieces per box
         auto stages = [&]<int NJ>(std::integral_constant<int, NJ>) {
@@ -684,16 +705,8 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
         const float sd = ct.x * cl0 - ct.y * sl0;                   //                                      sin(lon - l0)
 #pragma unroll
         for (int k = 0; k < NPX; ++k) {
-            Taps t;
-            if (OMNI_DBG(a, 1)) { t.x0 = xa + 1; t.x1 = xa + 2; t.y0 = ymin; t.y1 = ymin; t.wa = t.wb = t.wc = t.wd = 0.25f * rt[k].x; (void)cd; (void)sd; }
-            else p2e_taps_core(a, sp, cp, rt[k].x, rt[k].y, cd, sd, t);
-            const float wsum = (t.wa + t.wb) + (t.wc + t.wd);       // all >= 0 after the threshold
-            l1[k] += wsum;
-            const int xo = t.x0 - xa_adj(t.x0, t.x1, xa);           // (see p2e_lds_kernel: the pair's SECOND element is the x1 tap at the right edge)
-            const bool used = wsum > 0.0f;
-            r0[k] = used ? (t.y0 - ymin) * pitch + xo : 0;
-            r1[k] = used ? (t.y1 - ymin) * pitch + xo : 0;
-            wa[k] = t.wa; wb[k] = t.wb; wc[k] = t.wc; wd[k] = t.wd;
+            if (OMNI_DBG(a, 1)) { r0[k] = r1[k] = 1; wa[k] = wb[k] = wc[k] = wd[k] = 0.25f * rt[k].x; l1[k] += rt[k].x; (void)cd; (void)sd; continue; }
+            l1[k] += p2e_taps_box(a, sp, cp, rt[k].x, rt[k].y, cd, sd, xa + 1, ymin, pitch, r0[k], r1[k], wa[k], wb[k], wc[k], wd[k]);   // (see p2e_lds_kernel)
         }
     };
 
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
             for (int q = 0; q < NJ; ++q) {
                 const int qc = q * 64 + lane;
                 const int rr = (int)(((float)qc + 0.5f) * rbw);                        // qc / bw4, exact for qc, bw4 <= 1024
-                g[q] = qc < nchunk ? (unsigned)rr * sYb + (unsigned)(qc - rr * bw4) * 16u : 0x80000000u;   // past the end (of THIS patch's box): zeros
+                g[q] = qc < nchunk ? (unsigned)__umul24((unsigned)rr, sYb) + (unsigned)(qc - __mul24(rr, bw4)) * 16u : 0x80000000u;   // past the end (of THIS patch's box): zeros  (row pitch < 2^24 bytes: host-checked)
             }
         };
         auto issue = [&](const unsigned (&g)[P2W_NJMAX], unsigned base, int plane, int slot_i) {
@@ -832,6 +845,13 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
     }
 }
 
+// ------------------------------------------------------------------ (round 5: ONE plane per wave with D = 2 / 3 patches in flight, measured and dropped)
+// p2e_walk1_kernel kept the boxes of D consecutive patches of a single-plane tile in flight (the flat pipeline above holds ONE stage when a stage is a
+// whole patch).  Same bits; BASELINE cfg 5 fp16 108.8 / 115.3 / 106.2 us and cfg 3 27.1 / 27.5 / 29.9 us for D = 1 / 2 / 3, same box
+// (profiles/r05c_p2e_single_plane.txt): the one-plane blend is not waiting for its boxes.  Neither is it short of issue slots: 24 % fewer VALU
+// instructions in the tap section (p2e_taps_box: validity on two factors, 24-bit index arithmetic — kept) changed nothing either.  With parts switched
+// off (debug build): no tap geometry -47 us, no LDS reads -14, no DMA -1.5, no stores -6, everything off 54 us of 113: half of the kernel is the per-(wave,
+// patch) skeleton — records, box parameters, the stage switch — which only MORE PIXELS PER WAVE (8-row tiles: new tile / box tables) would amortise.
 // ------------------------------------------------------------------ (round 3: a plane-major form of this kernel, measured and dropped)
 // p2e_tile_kernel swapped the loops: set-up once per tile (all table entries and patch constants in one batch of scalar loads, the taps of
 // EVERY covering patch in registers, 6 per pixel and patch), then ONE pipeline of PL stages per tile, a stage = the boxes of all covering
@@ -964,7 +984,8 @@ int launch_p2e_lds_pl(const P2EArgs& a, const omni_geometry* g, int p_first, int
     // 25.7 us, 110 -> 100 us (fp16), 105 -> 88 us — where its small LDS footprint (one stage) admits 24-32 waves per CU; with 4 / 8 planes per wave the
     // two kernels measure equal at 8 panoramas and p2e_lds_kernel 3 % ahead at 16 (profiles/r04_p2e_walk.txt) | 2: always | 0: never
     if constexpr (p2w_fits<T, PL, CONF>())
-    if ((omni_options().p2e_walk == 2 || (omni_options().p2e_walk == 1 && PL <= 2)) && g->p2e_tiles[sizeof(T) == 2 ? 1 : 0].walk && g->p2e_tiles[sizeof(T) == 2 ? 1 : 0].max_chunks <= 64 * P2W_NJMAX)
+    if ((omni_options().p2e_walk == 2 || (omni_options().p2e_walk == 1 && PL <= 2)) && g->p2e_tiles[sizeof(T) == 2 ? 1 : 0].walk && g->p2e_tiles[sizeof(T) == 2 ? 1 : 0].max_chunks <= 64 * P2W_NJMAX &&
+        (unsigned long long)a.sY * sizeof(T) < (1ull << 24))          // (its DMA offsets use the full-rate 24-bit multiply on the row pitch)
         return launch_p2e_walk_pl<T, PL, CONF>(a, g, p_first, planes, tensor_bytes, stream);
     int nb = omni_options().p2e_nbuf;
     if (nb <= 0) nb = 2;   // measured: 2 stages x 16 waves/CU beat 4 stages (18.4 vs 19.3 us at B=8 18x256^2)

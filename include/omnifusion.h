@@ -325,8 +325,9 @@ int omni_preprocess_depth_u16(const unsigned short* src, float* depth, unsigned 
  *   :96 cv2.imread(path, -1)  -> kind 1: the file's own samples, single-channel gray only: uint8 or uint16 (host byte order) [H,W]
  * `data` is the file's bytes; omni_png_info reads the header only.  Colour types 0/2/3/4/6 at 8 bits, 0/2/4/6 at 16 bits, not interlaced;
  * anything else returns OMNI_ERR_UNSUPPORTED, a damaged stream (signature, chunk CRC, zlib, size) OMNI_ERR_INVALID.
- * omni_png_decode_batch decodes n files of one size on `threads` host threads (0: one per hardware thread) — the loader's worker pool
- * (test.py:90-97 uses 8 DataLoader workers); dsts[i] may point into pinned memory so that the H2D copy needs no staging. */
+ * omni_png_decode_batch decodes n files of one size on the library's persistent decoder pool (one thread per core, at most 64, started on first use;
+ * `threads`: at most that many of THIS call's images at a time, 0: no limit, 1: in the calling thread) — the loader's worker pool (test.py:90-97 uses 8
+ * DataLoader workers); several calls may run side by side; dsts[i] may point into pinned memory so that the H2D copy needs no staging. */
 int omni_png_info(const void* data, size_t nbytes, int* width, int* height, int* bit_depth, int* color_type);
 int omni_png_decode(const void* data, size_t nbytes, void* dst, int H, int W, int kind);
 int omni_png_decode_batch(const void* const* datas, const size_t* nbytes, void* const* dsts, int n, int H, int W, int kind, int threads);

@@ -15,6 +15,9 @@
 #include <zlib.h>
 #include <string.h>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <new>
 #include <stdexcept>
 #include <thread>
@@ -226,35 +229,85 @@ extern "C" int omni_png_decode(const void* data, size_t nbytes, void* dst, int H
     return png_decode((const unsigned char*)data, nbytes, dst, H, W, kind, nullptr);
 }
 
-// n files on `threads` workers (0: one per hardware thread, at most n).  dsts[i] receives image i; the first failure's status is returned and its
-// message kept (the other images are still decoded).
+// A process-wide pool of decoder threads, started on first use: a batch call used to create (and join) its own std::threads — with several batch
+// decoders side by side that was ~18 000 thread creations per second, each an 8-MB stack mmap / munmap under the process's address-space lock, and the
+// whole loader levelled off at 2300 panoramas/s whatever the number of decoders (round 5, tools/png_fed_ab.py).
+namespace {
+class PngPool {
+public:
+    static PngPool& get() { static PngPool p; return p; }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); } cv_.notify_one(); }
+    int size() const { return (int)th_.size(); }
+private:
+    PngPool()
+    {
+        int n = (int)std::thread::hardware_concurrency();
+        n = std::max(2, std::min(n > 0 ? n / 2 : 8, 64));          // one decoder per core (two hardware threads each), at most 64
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+    }
+    ~PngPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) return;
+                f = std::move(q_.front()); q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> th_; bool stop_ = false;
+};
+}  // namespace
+
+// n files decoded on the library's decoder pool (threads: at most that many of this call's images at a time; 0: no limit; 1: in the calling thread).
+// dsts[i] receives image i; the first failure's status is returned and its message kept (the other images are still decoded).
 extern "C" int omni_png_decode_batch(const void* const* datas, const size_t* nbytes, void* const* dsts, int n, int H, int W, int kind, int threads)
 {
     if (n < 0 || (n > 0 && (!datas || !nbytes || !dsts))) OMNI_FAIL(OMNI_ERR_INVALID, "omni_png_decode_batch: null argument");
     if (kind != 0 && kind != 1) OMNI_FAIL(OMNI_ERR_INVALID, "omni_png_decode_batch: kind must be 0 or 1");
     if (n == 0) return OMNI_OK;
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    nt = std::max(1, std::min(nt, n));
-    std::atomic<int> next(0), status(OMNI_OK);
-    std::string first_error;
-    std::mutex mu;
-    auto work = [&]() {
+    struct Call {
+        std::atomic<int> next{0}, left{0}, status{OMNI_OK};
+        std::string first_error; std::mutex mu; std::condition_variable done;
+    } call;
+    auto work = [&]() {                                             // takes images until none is left (a pool thread, or the caller)
         for (;;) {
-            const int i = next.fetch_add(1);
+            const int i = call.next.fetch_add(1);
             if (i >= n) return;
             int rc = (datas[i] && dsts[i]) ? png_decode((const unsigned char*)datas[i], nbytes[i], dsts[i], H, W, kind, nullptr) : OMNI_ERR_INVALID;
             if (rc != OMNI_OK) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (status.load() == OMNI_OK) { status.store(rc); first_error = "image " + std::to_string(i) + ": " + omni_last_error(); }
+                std::lock_guard<std::mutex> lk(call.mu);
+                if (call.status.load() == OMNI_OK) { call.status.store(rc); call.first_error = "image " + std::to_string(i) + ": " + omni_last_error(); }
             }
         }
     };
-    if (nt == 1) work();
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
-        for (auto& t : pool) t.join();
+    int helpers = 0;
+    if (threads != 1 && n > 1) {
+        helpers = std::min(n, PngPool::get().size());
+        if (threads > 1) helpers = std::min(helpers, threads);
+        helpers -= 1;                                               // the calling thread decodes too
     }
-    if (status.load() != OMNI_OK) omni_set_error("omni_png_decode_batch: " + first_error);
-    return status.load();
+    call.left.store(helpers);
+    for (int t = 0; t < helpers; ++t)
+        PngPool::get().submit([&call, &work] {
+            work();
+            std::lock_guard<std::mutex> lk(call.mu);                // (the notify under the lock: `call` lives on the caller's stack until it has seen left == 0)
+            if (call.left.fetch_sub(1) == 1) call.done.notify_all();
+        });
+    work();
+    if (helpers > 0) {
+        std::unique_lock<std::mutex> lk(call.mu);
+        call.done.wait(lk, [&] { return call.left.load() == 0; });
+    }
+    if (call.status.load() != OMNI_OK) omni_set_error("omni_png_decode_batch: " + call.first_error);
+    return call.status.load();
 }

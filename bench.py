@@ -70,8 +70,10 @@ def cpu_baseline():
     from oracle import c_oracle as co, model_ref
     from omnifusion_amd.weights import make_state_dict
     co.build()
+    from omnifusion_amd.png import effective_cpus
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
+    granted = effective_cpus()                  # the container's CPU-time quota: the GPU boxes of this pool show 256 hardware threads and grant 16 CPUs
     sd = make_state_dict(42, NPATCH, False)
     rgb = torch.rand((1, 3, ERP_H, ERP_W), generator=torch.Generator().manual_seed(0))
 
@@ -89,9 +91,9 @@ def cpu_baseline():
     n, dt = run(threads, 10.0, 8)
     n1, dt1 = run(1, 8.0, 2)
     _omp_threads(threads)
-    return {"value": n / dt, "unit": "panoramas/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "panoramas/s", "cores": threads, "cpus_granted": granted, "kind": "port",
             "value_1thread": n1 / dt1, "s_per_panorama_1thread": dt1 / n1, "s_per_panorama": dt / n,
-            "sample": f"{n} panorama(s) 512x1024 on {threads} threads + {n1} on 1 thread: single-pass model P=128 confidence=True, torch-CPU fp32 oracle "
+            "sample": f"{n} panorama(s) 512x1024 on {threads} threads ({granted} CPUs granted by the container's cgroup quota) + {n1} on 1 thread: single-pass model P=128 confidence=True, torch-CPU fp32 oracle "
                       f"+ C/OpenMP equi2pers/pers2equi (the reference's own dense tables are not re-read per call here: this port is faster than the reference's Python)"}
 
 
@@ -209,6 +211,7 @@ def png_fed_rate(run, depth, dev, B, src_hw, nfiles, budget_s, pending):
     base = synthetic_photo(Hs, Ws, 900)
     files = [encode_png_bgr(np.roll(base, (131 * k, 517 * k), axis=(0, 1))) for k in range(nfiles)]     # distinct files, one synthesis
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    granted = png.effective_cpus()
     probe = png.PngBatches([files[i % nfiles] for i in range(B * 64)], B, threads=0, pinned=True)
     workers = probe.workers
     t0, nb = time.perf_counter(), 0                                           # the decode pool alone (no GPU work): the loader's ceiling
@@ -241,8 +244,8 @@ def png_fed_rate(run, depth, dev, B, src_hw, nfiles, budget_s, pending):
     rate = B * (nbatch - nskip) / (time.perf_counter() - tf)
     raw_mb = Hs * Ws * 3 / 1e6
     return {"panoramas_per_s_per_gpu": rate, "file_size": [Hs, Ws], "file_MB": float(np.mean([len(f) for f in files])) / 1e6, "decoded_MB": raw_mb,
-            "host_threads": ncpu, "decode_workers": workers, "decode_threads_busy": workers * B,          # (a PNG is one deflate stream: one thread per image)
-            "decode_pool_alone_panoramas_per_s": pool_rate, "decode_MBps_per_thread": pool_rate * raw_mb / (workers * B), "batches": nbatch}
+            "host_threads": ncpu, "cpus_granted": granted, "decode_workers": workers,                    # (a PNG is one deflate stream: one thread per image; the container's quota caps the pool)
+            "decode_pool_alone_panoramas_per_s": pool_rate, "decode_MBps_per_granted_cpu": pool_rate * raw_mb / max(1, min(granted, workers * B)), "batches": nbatch}
 
 
 def pmc_traffic(B, name="resample_traffic.json"):
@@ -441,7 +444,7 @@ def main():
         png_fed = {"files_512x1024": png_fed_rate(run, depth, dev, B, (ERP_H, ERP_W), 16, 4.0, pending),
                    "files_2048x4096": png_fed_rate(run, depth, dev, B, (2048, 4096), 8, 4.0, pending),
                    "note": "PNG files (in memory: the page cache's role) -> omni_png_decode_batch on every host thread this rank may use, one batch ahead "
-                           "(png.PngBatches) -> pinned buffer ring -> DeviceFeeder -> prep_rgb_kernel (INTER_AREA resize on the GPU for the 2048x4096 "
+                           "(png.PngBatches; the decoder pool is sized to the CPUs the container GRANTS — cpus_granted — not to the hardware threads it shows) -> pinned buffer ring -> DeviceFeeder -> prep_rgb_kernel (INTER_AREA resize on the GPU for the 2048x4096 "
                            "files = Stanford2D3D's native panoramas, dataset_loader_stanford.py:92-97) -> pipelined forward; synthetic photo-like "
                            "content, filters Sub/Up/Average/Paeth by rows.  decode_pool_alone = the decode pool with no GPU work: the loader's ceiling"}
     # the link itself: one pinned 12.6-MB batch of frames, host -> device, back to back

@@ -14,6 +14,8 @@
 // interlacing (Adam7) and no 1/2/4-bit samples (OMNI_ERR_UNSUPPORTED; neither occurs in the dataset).
 #include <zlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -242,7 +244,17 @@ private:
     PngPool()
     {
         int n = (int)std::thread::hardware_concurrency();
-        n = std::max(2, std::min(n > 0 ? n / 2 : 8, 64));          // one decoder per core (two hardware threads each), at most 64
+        n = std::max(2, std::min(n > 0 ? n / 2 : 8, 64));          // one decoder per core (two hardware threads each), at most 64 ...
+        // ... and no more than the CPU time the container may use (cgroup v2 cpu.max "quota period" / v1 cfs quota): the GPU boxes of this pool show 256
+        // hardware threads and grant 16 CPUs — 64 decoder threads there only take turns
+        long long quota = -1, period = 100000;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[32] = {0}; if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q); fclose(f); }
+        else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &period) != 1) period = 100000; fclose(f2); }
+        }
+        if (quota > 0 && period > 0) n = std::max(2, std::min(n, (int)((quota + period - 1) / period)));
         for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
     }
     ~PngPool()

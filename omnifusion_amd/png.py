@@ -17,6 +17,24 @@ import torch
 from . import _lib
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the container's CPU-time quota (cgroup v2 `cpu.max` / v1 cfs quota) — a box
+    can show 256 hardware threads and grant 16 CPUs; threads beyond that only take turns."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def _bytes_of(src):
     if isinstance(src, (bytes, bytearray, memoryview)):
         return bytes(src)
@@ -74,12 +92,12 @@ class PngBatches:
     k+workers runs while batch k crosses PCIe and the network) — the role of the reference's 8 DataLoader workers (test.py:90-97) for the
     decode step.  A PNG is one deflate stream: an image occupies ONE thread, so a batch of 8 keeps 8 host threads busy whatever the pool's
     size (round 5 measured 1100 panoramas/s that way against 3800 consumed): several batches are decoded side by side, delivered in order.
-    workers = 0: as many as the host's cores allow at `batch` threads each, at most 16."""
+    workers = 0: enough batches side by side to keep the CPUs this process is GRANTED busy (`effective_cpus`), 2 .. 16."""
 
     def __init__(self, paths, batch, threads=0, pinned=True, ring=0, workers=0):
         self.paths, self.batch, self.threads, self.pinned = list(paths), int(batch), int(threads), pinned
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        self.workers = int(workers) if workers > 0 else max(1, min(16, ncpu // (2 * max(1, self.batch))))   # (two hardware threads per core: one decoder per core)
+        ncpu = effective_cpus()
+        self.workers = int(workers) if workers > 0 else max(2, min(16, ncpu // max(1, self.batch) + 1))   # enough batches in work to keep every granted CPU decoding
         self.ring = max(2, int(ring), self.workers + 1)            # decoded-but-unconsumed batches (= buffers in flight)
         self._pool, self._pool_lock = [], threading.Lock()         # buffers handed back by the consumer: (tensor, event or None)
 

@@ -171,7 +171,7 @@ def test_png_batches_abandoned_iterator_and_buffer_recycling():
     while threading.active_count() > before and time.time() - t0 < 5:
         time.sleep(0.05)
     assert threading.active_count() == before
-    pb = png.PngBatches(files, 3, threads=2, pinned=False, ring=3)
+    pb = png.PngBatches(files, 1, threads=2, pinned=False, ring=3, workers=2)       # 12 batches through <= 5 buffers
     seen, ptrs = [], set()
     for b in pb:
         seen.append(b.numpy().copy())

@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <new>
 #include <stdexcept>
 #include <thread>
@@ -290,15 +291,18 @@ extern "C" int omni_png_decode_batch(const void* const* datas, const size_t* nby
     struct Call {
         std::atomic<int> next{0}, left{0}, status{OMNI_OK};
         std::string first_error; std::mutex mu; std::condition_variable done;
-    } call;
-    auto work = [&]() {                                             // takes images until none is left (a pool thread, or the caller)
+    };
+    // (shared with the helpers: the last helper may still be inside its unlock / notify when the caller wakes up and returns)
+    const std::shared_ptr<Call> callp = std::make_shared<Call>();
+    Call& call = *callp;
+    auto work = [&, callp]() {                                      // takes images until none is left (a pool thread, or the caller)
         for (;;) {
-            const int i = call.next.fetch_add(1);
+            const int i = callp->next.fetch_add(1);
             if (i >= n) return;
             int rc = (datas[i] && dsts[i]) ? png_decode((const unsigned char*)datas[i], nbytes[i], dsts[i], H, W, kind, nullptr) : OMNI_ERR_INVALID;
             if (rc != OMNI_OK) {
-                std::lock_guard<std::mutex> lk(call.mu);
-                if (call.status.load() == OMNI_OK) { call.status.store(rc); call.first_error = "image " + std::to_string(i) + ": " + omni_last_error(); }
+                std::lock_guard<std::mutex> lk(callp->mu);
+                if (callp->status.load() == OMNI_OK) { callp->status.store(rc); callp->first_error = "image " + std::to_string(i) + ": " + omni_last_error(); }
             }
         }
     };
@@ -310,10 +314,10 @@ extern "C" int omni_png_decode_batch(const void* const* datas, const size_t* nby
     }
     call.left.store(helpers);
     for (int t = 0; t < helpers; ++t)
-        PngPool::get().submit([&call, &work] {
-            work();
-            std::lock_guard<std::mutex> lk(call.mu);                // (the notify under the lock: `call` lives on the caller's stack until it has seen left == 0)
-            if (call.left.fetch_sub(1) == 1) call.done.notify_all();
+        PngPool::get().submit([callp, &work] {
+            work();                                                 // (`work` and what it references live on the caller's stack: the caller does not return before left == 0)
+            std::lock_guard<std::mutex> lk(callp->mu);
+            if (callp->left.fetch_sub(1) == 1) callp->done.notify_all();
         });
     work();
     if (helpers > 0) {

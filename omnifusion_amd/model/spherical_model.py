@@ -76,13 +76,14 @@ class _Pending:
         return self._out
 
 
-def _concurrent_streams(n, device, candidates=12, spin=400_000):
+def _concurrent_streams(n, device, candidates=12, spin=400_000, first=None):
     """n streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by default) and two
     streams on one queue serialise — which pairs collide depends on every stream created before, so it is MEASURED: two spin
-    kernels on a pair of candidate streams take T when the queues differ and 2T when they are the same."""
+    kernels on a pair of candidate streams take T when the queues differ and 2T when they are the same.
+    `first`: a stream the caller already works on (the others are chosen to run beside IT)."""
     import time
     dev = torch.device(device)
-    cand = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    cand = ([first] if first is not None else []) + [torch.cuda.Stream(device=dev) for _ in range(candidates)]
 
     def spin_pair(a, b):
         torch.cuda.synchronize(dev)
@@ -383,7 +384,14 @@ class spherical_fusion(nn.Module):
     def _network_lanes(self, patches, pf, bs, confidence):
         e = self._eng
         if self._lanes is None:                                            # reset by _sync_packed whenever the weights were repacked
-            self._lanes = [(e, None)] + [(e.lane(), torch.cuda.Stream(device=patches.device)) for _ in range(self.LANES - 1)]
+            # the other lanes' streams must sit on other hardware queues than THIS stream (a fresh torch.cuda.Stream may share its queue: the lanes then
+            # run one after the other — round 5 met a process whose forwards took 4.4 instead of 2.5 ms that way); measured, once per packing
+            cur0 = torch.cuda.current_stream(patches.device)
+            if torch.cuda.is_current_stream_capturing():
+                side = [torch.cuda.Stream(device=patches.device) for _ in range(self.LANES - 1)]
+            else:
+                side = _concurrent_streams(self.LANES, patches.device, first=cur0)[1:]
+            self._lanes = [(e, None)] + [(e.lane(), st) for st in side]
         N, P = self.npatches, e.patch_size[0]
         a = torch.empty((bs, N, 1, P, P), dtype=torch.float32, device=patches.device)
         c = torch.empty_like(a) if confidence else None

@@ -61,6 +61,7 @@ const OptName kOpts[] = {
     {"p2e_nbuf", "OMNI_P2E_NBUF", &OmniOptions::p2e_nbuf, 0},
     {"p2e_planes", "OMNI_P2E_PLANES", &OmniOptions::p2e_planes, 0},
     {"p2e_walk", "OMNI_P2E_WALK", &OmniOptions::p2e_walk, 1},
+    {"p2e_tile8", "OMNI_P2E_TILE8", &OmniOptions::p2e_tile8, 1},
     {"p2e_store", "OMNI_P2E_STORE", &OmniOptions::p2e_store, 1},
     {"geom_cache_max", "OMNI_GEOM_CACHE_MAX", &OmniOptions::geom_cache_max, 16},
 };

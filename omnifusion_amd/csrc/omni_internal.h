@@ -59,6 +59,7 @@ struct OmniOptions {
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
     int p2e_store;        // OMNI_P2E_STORE      ERP stores of the pers2equi LDS kernels: 1 (default) non-temporal | 0 plain
+    int p2e_tile8;        // OMNI_P2E_TILE8      1 (default): ONE plane per wave (a lone depth map) on 8 x 32 ERP tiles, four pixels per lane | 0: 4 x 32 like every other form (same bits)
     int p2e_walk;         // OMNI_P2E_WALK       1 (default): the flat-pipeline kernel p2e_walk_kernel (one stage stream per tile across its patches, stages consumed in pairs) | 0: p2e_lds_kernel (patch by patch)
     int bwd_wide;         // OMNI_BWD_WIDE       1 (default): the backward gathers read a plane-interleaved copy of the gradient (16-byte gathers) | 0: the gradient itself (4-byte gathers, no scratch)
     int bwd_chunk;        // OMNI_BWD_CHUNK      blocks per XCD chunk of the backward gathers (0: 16; 4 .. 64 measured within 3 %)
@@ -123,7 +124,7 @@ struct omni_geometry {
     int ntx;
     // pers2equi LDS path: per ERP tile (P2E_TH x P2E_TW pixels) the list of covering patches with the bounding box of their
     // bilinear taps inside the patch (omni_pers2equi.hip); index 0: 4-byte elements, 1: 2-byte elements (16-byte chunk alignment)
-    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; int sum_chunks; uint2* ord; int nslots; unsigned char* walk; int nslots_walk; } p2e_tiles[2];   // ord: the table in block order (+ tile id), what the kernels read
+    struct P2ETiles { uint2* ent; int max_chunks; int max_cand; int ok; int sum_chunks; uint2* ord; int nslots; unsigned char* walk; int nslots_walk; } p2e_tiles[4];   // ord: the table in block order (+ tile id), what the kernels read; [2], [3]: the 8-row tile sets of the one-plane walk kernel (walk table only)
     int p2e_tx, p2e_ty;            // tiles per ERP row / column
     // pers2equi backward by gathers (omni_pers2equi.hip): per (patch, 4 x 32 patch tile) the ERP box of the pixels whose taps touch it
     // (columns relative to the patch's centre column: the box may cross the +-pi seam), and 1 / (L1 norm of the tap weights) per ERP pixel

@@ -315,6 +315,7 @@ constexpr int P2E_MAX_CHUNKS = 64 * P2E_NJMAX;
 
 // entry: x = n | bw4 << 6 | bh << 16 | (entry 0 only) count << 26 (bw4 = 16-byte chunks per box row, bh = box rows, both <= 512;
 // count = covering patches of the tile), y = xa | ymin << 16
+template <int TH>                                                  // tile height: P2E_TH (every LDS kernel) or 8 (the one-plane walk kernel, round 5)
 __global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __restrict__ ent, int tiles_x, int ntiles, int epc,
                                                         int* __restrict__ stats)
 {
@@ -329,8 +330,8 @@ __global__ __launch_bounds__(256) void p2e_tiles_kernel(P2EArgs a, uint2* __rest
     for (int n = 0; n < a.tab.N; ++n) {
         int xmin = 0x7fffffff, xmax = -1, ymin = 0x7fffffff, ymax = -1;
 #pragma unroll
-        for (int k = 0; k < P2E_NPX; ++k) {
-            const int i = ti * P2E_TH + rsub + 2 * k;
+        for (int k = 0; k < TH / 2; ++k) {
+            const int i = ti * TH + rsub + 2 * k;
             const bool iin = i < a.H;
             const float2 rt = a.row_trig[iin ? i : a.H - 1];
             Taps t;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(64, 4) void p2e_lds_kernel(P2EArgs a, const uint2* 
 constexpr int P2W_NJMAX = 6;                                   // largest box (KiB) the walk kernel is instantiated for
 constexpr int P2W_SLOT = 768;                                  // bytes per block slot: header 32 | 12 patch records x 32 | trig 288 | pad
 constexpr int P2W_OFF_PATCH = 32, P2W_OFF_TRIG = 32 + 32 * P2E_MAXC;
-static_assert(P2W_OFF_TRIG + 8 * (P2E_TW + P2E_TH) <= P2W_SLOT, "slot layout");
+static_assert(P2W_OFF_TRIG + 8 * (P2E_TW + 8) <= P2W_SLOT, "slot layout (8-row tiles included)");
 constexpr int p2w_nb(int pieces, int pl)
 {
     int nb = P2E_RING_KB / pieces >= 4 ? 4 : P2E_RING_KB / pieces >= 2 ? 2 : 1;
@@ -645,11 +646,15 @@ constexpr int p2w_nb(int pieces, int pl)
 constexpr int p2w_u(int nb, int pl) { return nb == 4 ? 2 : (nb == 2 && pl == 2) ? 2 : 1; }
 
 constexpr int P2W_WPB = 1;                                     // waves per block: independent waves (no barrier, each its own tile and ring) — 4x fewer workgroups to dispatch
-template <typename T, int PL, bool CONF>
-__global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? (CONF ? 5 : 6) : 4) void p2e_walk_kernel(P2EArgs a, const unsigned char* __restrict__ table, int tiles_x, unsigned tensor_bytes, int p_first, unsigned ring_bytes)
+// TH: rows of the ERP tile a wave owns (TH / 2 pixels per lane).  8 for ONE plane per wave (round 5): what a lone depth map costs is not bytes, tap
+// instructions or box latency (profiles/r05c_p2e_single_plane.txt) but the per-(wave, patch) set-up — four panoramas through the 4-plane form take 48 us
+// per plane where one takes 105: with twice the pixels per wave the set-up is paid half as often.  Same taps, same candidate order, same blend
+// expression per pixel (a patch that does not cover a pixel adds an exact 0): the bits do not depend on the tile.
+template <typename T, int PL, bool CONF, int TH = P2E_TH>
+__global__ __launch_bounds__(64 * P2W_WPB, TH > P2E_TH ? (CONF ? 4 : 5) : PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? (CONF ? 5 : 6) : 4) void p2e_walk_kernel(P2EArgs a, const unsigned char* __restrict__ table, int tiles_x, unsigned tensor_bytes, int p_first, unsigned ring_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char p2w_smem_all[];    // the ONLY LDS object of this kernel: one ring per wave
-    constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = P2E_NPX;
+    constexpr int EPC = 16 / (int)sizeof(T), M = CONF ? 2 : 1, NPX = TH / 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char* const p2w_smem = p2w_smem_all + (unsigned)wv * ring_bytes;
     const unsigned char* __restrict__ slot = table + ((size_t)blockIdx.x * P2W_WPB + (size_t)wv) * P2W_SLOT;
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(64 * P2W_WPB, PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? 
     const size_t erp_plane = (size_t)a.H * a.W;
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
-        const int i = ti * P2E_TH + rsub + 2 * k;
+        const int i = ti * TH + rsub + 2 * k;
         if (!(jin && i < a.H)) continue;
         if (OMNI_DBG(a, 8) && l1[k] != -1.0f) continue;
         const float rden = 1.0f / fmaxf(l1[k], 1e-12f);
@@ -962,6 +967,17 @@ int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int p_first, int
 template <typename T, int PL, bool CONF>
 int launch_p2e_walk_pl(const P2EArgs& a, const omni_geometry* g, int p_first, int planes, size_t tensor_bytes, hipStream_t stream)
 {
+    if constexpr (PL == 1) {
+        // ONE plane per wave: the 8-row tile set where the geometry has one whose boxes fit (option p2e_tile8: 1 (default) | 0: 4-row tiles)
+        const auto& t8 = g->p2e_tiles[2 + (sizeof(T) == 2 ? 1 : 0)];
+        if (omni_options().p2e_tile8 && t8.walk && t8.max_chunks <= 64 * P2W_NJMAX && P2W_WPB == 1) {
+            const size_t lds8 = (size_t)((t8.max_chunks + 63) / 64 * (CONF ? 2 : 1)) * 1024;
+            hipLaunchKernelGGL((p2e_walk_kernel<T, 1, CONF, 8>), dim3(t8.nslots_walk, planes), dim3(64), lds8, stream, a,
+                               (const unsigned char*)t8.walk, g->p2e_tx, (unsigned)tensor_bytes, p_first, (unsigned)lds8);
+            OMNI_HIP(hipGetLastError());
+            return OMNI_OK;
+        }
+    }
     const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
     const int stage_kb = (tt.max_chunks + 63) / 64 * (CONF ? 2 : 1);
     // (ONE plane per wave keeps one stage in flight whatever the ring: its LDS is the largest stage of the geometry, 1-2 KiB — up to 32 waves per CU)
@@ -1078,16 +1094,21 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
     int rc = fill_args(a, g, nullptr, nullptr, nullptr, 0, 1, OMNI_LAYOUT_BNCHW);
     if (rc != OMNI_OK) return rc;
     g->p2e_tx = (g->W + P2E_TW - 1) / P2E_TW; g->p2e_ty = (g->H + P2E_TH - 1) / P2E_TH;
-    const long long ntiles = (long long)g->p2e_tx * g->p2e_ty;
-    if (ntiles >= (1ll << 28)) return OMNI_OK;                     // absurd sizes: gather path only
+    if ((long long)g->p2e_tx * g->p2e_ty >= (1ll << 28)) return OMNI_OK;                     // absurd sizes: gather path only
     int* dstats = nullptr;
     OMNI_HIP(hipMalloc((void**)&dstats, 3 * sizeof(int)));
-    for (int e = 0; e < 2; ++e) {
+    // sets 0 / 1: P2E_TH-row tiles (4- / 2-byte elements), what every LDS kernel reads; sets 2 / 3: 8-row tiles for the one-plane walk kernel (its slot
+    // table only; built when the 4-row set of the element size exists)
+    for (int e = 0; e < 4; ++e) {
         auto& tt = g->p2e_tiles[e];
-        const int epc = e ? 8 : 4;
+        const int epc = (e & 1) ? 8 : 4, TH = e < 2 ? P2E_TH : 8;
+        if (e >= 2 && (!g->p2e_tiles[e - 2].ok || !omni_options().p2e_tile8)) continue;
+        const int ty_set = (g->H + TH - 1) / TH;
+        const long long ntiles = (long long)g->p2e_tx * ty_set;
         if (hipMalloc((void**)&tt.ent, sizeof(uint2) * (size_t)ntiles * P2E_MAXC) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: out of memory"); }
         if (hipMemsetAsync(dstats, 0, 3 * sizeof(int), stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: memset"); }
-        hipLaunchKernelGGL(p2e_tiles_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, a, tt.ent, g->p2e_tx, (int)ntiles, epc, dstats);
+        if (TH == 8) hipLaunchKernelGGL(p2e_tiles_kernel<8>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, a, tt.ent, g->p2e_tx, (int)ntiles, epc, dstats);
+        else         hipLaunchKernelGGL(p2e_tiles_kernel<P2E_TH>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, a, tt.ent, g->p2e_tx, (int)ntiles, epc, dstats);
         int hs[3] = {0, 0, 0};
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, dstats, sizeof(hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: kernel failed"); }
@@ -1104,7 +1125,7 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
             // XCD the tiles sorted by cost and dealt to the 32 round-robin positions in snake order.  Pure speed: any order is correct.
             std::vector<uint2> he((size_t)ntiles * P2E_MAXC);
             if (hipMemcpy(he.data(), tt.ent, sizeof(uint2) * he.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: copy"); }
-            const int tx = g->p2e_tx, ty = g->p2e_ty, band = omni_options().p2e_band > 0 ? omni_options().p2e_band : std::max(1, ty / 8), nbands = (ty + band - 1) / band;   // (one contiguous range of tile rows per XCD: 15.8 us, FETCH 52 MB; 8-row bands 16.0, 4-row 17.2 / 61 MB, 2-row 19.6 / 85 MB)
+            const int tx = g->p2e_tx, ty = ty_set, band = omni_options().p2e_band > 0 ? omni_options().p2e_band : std::max(1, ty / 8), nbands = (ty + band - 1) / band;   // (one contiguous range of tile rows per XCD: 15.8 us, FETCH 52 MB; 8-row bands 16.0, 4-row 17.2 / 61 MB, 2-row 19.6 / 85 MB)
             auto cost = [&](int wid) { return 2 + (int)(he[(size_t)wid * P2E_MAXC].x >> 26); };
             std::vector<std::pair<long long, int>> bc(nbands);
             for (int b = 0; b < nbands; ++b) {
@@ -1144,8 +1165,8 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
                         rec[4 * (c + 1) + 2] = make_uint2(fbits(g->p2e.sphi[n]), fbits(g->p2e.cphi[n]));
                     }
                 }
-            if (hipMalloc((void**)&tt.ord, sizeof(uint2) * ord.size()) != hipSuccess ||
-                hipMemcpy(tt.ord, ord.data(), sizeof(uint2) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: order table"); }
+            if (e < 2 && (hipMalloc((void**)&tt.ord, sizeof(uint2) * ord.size()) != hipSuccess ||
+                hipMemcpy(tt.ord, ord.data(), sizeof(uint2) * ord.size(), hipMemcpyHostToDevice) != hipSuccess)) { (void)hipFree(dstats); OMNI_FAIL(OMNI_ERR_HIP, "omni_p2e_build_tiles: order table"); }
             // ---- the same slots for p2e_walk_kernel: header {tile | -1, covering patches, pieces per stage (tile-uniform)}, the patch records, the tile's trig
             {
                 std::vector<float2> hrow((size_t)g->H), hcol((size_t)g->W);
@@ -1178,7 +1199,7 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
                         const int ti = wid / tx, tj = wid - ti * tx;
                         float2* tg = reinterpret_cast<float2*>(dst + P2W_OFF_TRIG);
                         for (int cc = 0; cc < P2E_TW; ++cc) tg[cc] = hcol[(size_t)std::min(tj * P2E_TW + cc, g->W - 1)];
-                        for (int r = 0; r < P2E_TH; ++r) tg[P2E_TW + r] = hrow[(size_t)std::min(ti * P2E_TH + r, g->H - 1)];
+                        for (int r = 0; r < TH; ++r) tg[P2E_TW + r] = hrow[(size_t)std::min(ti * TH + r, g->H - 1)];
                     }
                 }
                 if (omni_options().e2p_verbose)
@@ -1191,7 +1212,7 @@ int omni_p2e_build_tiles(omni_geometry* g, hipStream_t stream)
         (void)hipFree(tt.ent); tt.ent = nullptr;                     // the kernels read only the ordered table (tt.ord)
         if (omni_options().e2p_verbose)
             fprintf(stderr, "[omni] pers2equi %dx%d <- %d patches %dx%d, %d-byte elements: largest tap box %d chunks, <= %d patches and <= %d chunks per %dx%d tile -> %s\n",
-                    g->H, g->W, g->N, g->ph, g->pw, 16 / epc, hs[0], hs[1], hs[2], P2E_TH, P2E_TW, tt.ok ? "LDS path" : "gather path");
+                    g->H, g->W, g->N, g->ph, g->pw, 16 / epc, hs[0], hs[1], hs[2], TH, P2E_TW, tt.ok ? "LDS path" : "gather path");
     }
     (void)hipFree(dstats);
     return OMNI_OK;

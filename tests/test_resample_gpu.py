@@ -382,18 +382,20 @@ def test_flat_pipeline_kernel_gives_the_bits_of_the_other_two(cfg):
         try:
             return fn().clone()
         finally:
-            for k in opts: L.set_option(k, {"p2e_walk": 1, "p2e_gather": 0}[k])
+            for k in opts: L.set_option(k, {"p2e_walk": 1, "p2e_gather": 0, "p2e_tile8": 1}[k])
             lib.omni_geometry_cache_clear()
     for dt in (torch.float32, torch.float16):
         x = torch.rand((B, N, C, P, P), device=DEV).to(dt)
         f = lambda: pers2equi(x, (80, 80), nrows, (P, P), (H, W), None, layout=lay)
         walk, lds, gat = run(f, p2e_walk=2), run(f, p2e_walk=0, p2e_gather=2), run(f, p2e_gather=1)
         assert torch.equal(walk, lds) and torch.equal(walk, gat), f"{cfg} {dt}"
+        assert torch.equal(walk, run(f, p2e_walk=2, p2e_tile8=0)), f"{cfg} {dt}: 8-row against 4-row tiles of the one-plane form (round 5)"
         c = torch.rand((B, N, 1, P, P), device=DEV).to(dt)
         d = (torch.rand((B, N, 1, P, P), device=DEV) * 8.0).to(dt)
         fc = lambda: pers2equi_conf(d, c, (80, 80), nrows, (P, P), (H, W), layout=lay)
         walk, lds, gat = run(fc, p2e_walk=2), run(fc, p2e_walk=0, p2e_gather=2), run(fc, p2e_gather=1)
         assert torch.equal(walk, lds) and torch.equal(walk, gat), f"conf {cfg} {dt}"
+        assert torch.equal(walk, run(fc, p2e_walk=2, p2e_tile8=0)), f"conf {cfg} {dt}: 8-row against 4-row tiles"
 
 
 @pytest.mark.parametrize("cfg", [(8, 3, 512, 1024, 4, 256), (1, 3, 512, 1024, 4, 128), (3, 1, 512, 1024, 3, 128), (2, 2, 256, 512, 4, 64),

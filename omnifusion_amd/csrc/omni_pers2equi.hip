@@ -646,9 +646,8 @@ constexpr int p2w_nb(int pieces, int pl)
 constexpr int p2w_u(int nb, int pl) { return nb == 4 ? 2 : (nb == 2 && pl == 2) ? 2 : 1; }
 
 constexpr int P2W_WPB = 1;                                     // waves per block: independent waves (no barrier, each its own tile and ring) — 4x fewer workgroups to dispatch
-// TH: rows of the ERP tile a wave owns (TH / 2 pixels per lane).  8 for ONE plane per wave (round 5): what a lone depth map costs is not bytes, tap
-// instructions or box latency (profiles/r05c_p2e_single_plane.txt) but the per-(wave, patch) set-up — four panoramas through the 4-plane form take 48 us
-// per plane where one takes 105: with twice the pixels per wave the set-up is paid half as often.  Same taps, same candidate order, same blend
+// TH: rows of the ERP tile a wave owns (TH / 2 pixels per lane).  8 for ONE plane per wave (round 5): the per-(wave, patch) set-up — records, box
+// parameters, the stage switch — is paid half as often (cfg 5 fp32 96 -> 88 us, cfg 3 27.3 -> 26.3, fp16 unchanged: profiles/r05f_p2e_tile8.txt).  Same taps, same candidate order, same blend
 // expression per pixel (a patch that does not cover a pixel adds an exact 0): the bits do not depend on the tile.
 template <typename T, int PL, bool CONF, int TH = P2E_TH>
 __global__ __launch_bounds__(64 * P2W_WPB, TH > P2E_TH ? (CONF ? 4 : 5) : PL == 1 ? (CONF ? 6 : 8) : PL == 2 ? (CONF ? 5 : 6) : 4) void p2e_walk_kernel(P2EArgs a, const unsigned char* __restrict__ table, int tiles_x, unsigned tensor_bytes, int p_first, unsigned ring_bytes)
@@ -856,7 +855,9 @@ __global__ __launch_bounds__(64 * P2W_WPB, TH > P2E_TH ? (CONF ? 4 : 5) : PL == 
 // (profiles/r05c_p2e_single_plane.txt): the one-plane blend is not waiting for its boxes.  Neither is it short of issue slots: 24 % fewer VALU
 // instructions in the tap section (p2e_taps_box: validity on two factors, 24-bit index arithmetic — kept) changed nothing either.  With parts switched
 // off (debug build): no tap geometry -47 us, no LDS reads -14, no DMA -1.5, no stores -6, everything off 54 us of 113: half of the kernel is the per-(wave,
-// patch) skeleton — records, box parameters, the stage switch — which only MORE PIXELS PER WAVE (8-row tiles: new tile / box tables) would amortise.
+// patch) skeleton — records, box parameters, the stage switch.  MORE PIXELS PER WAVE (8-row tiles, TH = 8 above: half as many (wave, patch) pairs) bought
+// 8 % at fp32 (96 -> 88 us), 3 % at BASELINE cfg 3 and nothing at fp16: with 4.8 covering patches per ERP pixel at nrows 6 (2.1 at nrows 4; the oracle's cover count) the kernel is bound by the
+// instructions it spends per (pixel, patch), which no tile shape changes.
 // ------------------------------------------------------------------ (round 3: a plane-major form of this kernel, measured and dropped)
 // p2e_tile_kernel swapped the loops: set-up once per tile (all table entries and patch constants in one batch of scalar loads, the taps of
 // EVERY covering patch in registers, 6 per pixel and patch), then ONE pipeline of PL stages per tile, a stage = the boxes of all covering

@@ -1,5 +1,7 @@
 """Cost of building a geometry (tables of both operators) with and without the 8-row pers2equi tile set (option p2e_tile8): tools/geom_build_time.py"""
-import time, torch
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from omnifusion_amd import _lib as L
 from omnifusion_amd.equi_pers.pers2equi_v3 import pers2equi
 lib = L.load()

@@ -30,6 +30,8 @@ def p2e():
 
 XB = int(os.environ.get("XBITS", "0"))       # extra ablation bits OR-ed into the debug word (see the kernels' OMNI_DBG uses)
 BRIEF = os.environ.get("BRIEF", "0") == "1"
+FLUSH = os.environ.get("FLUSH", "0") == "1"
+flush = torch.empty((768 << 20) // 4, device=dev) if FLUSH else None
 
 
 def report(name, fn, env):
@@ -44,6 +46,8 @@ def report(name, fn, env):
     os.environ[env] = str(16 | XB)
     fn(); torch.cuda.synchronize()
     trace.zero_(); torch.cuda.synchronize()
+    if FLUSH:                                  # the traced launch reads its input from HBM: 768 MB written in between empty the 256-MB memory-side cache
+        flush.fill_(1.0); torch.cuda.synchronize()
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
     os.environ[env] = "0"
     tall = trace.cpu().numpy()

@@ -331,6 +331,13 @@ int omni_preprocess_depth_u16(const unsigned short* src, float* depth, unsigned 
 int omni_png_info(const void* data, size_t nbytes, int* width, int* height, int* bit_depth, int* color_type);
 int omni_png_decode(const void* data, size_t nbytes, void* dst, int H, int W, int kind);
 int omni_png_decode_batch(const void* const* datas, const size_t* nbytes, void* const* dsts, int n, int H, int W, int kind, int threads);
+/* The decoder's own inflate and checksums (csrc/omni_inflate.h), exposed so that they can be checked against an independent zlib (tests/test_png.py
+ * decodes the same valid, truncated and damaged streams with Python's zlib module): what cv2.imread gets from libpng -> libz.
+ * omni_zlib_inflate: one zlib stream (RFC 1950) -> at most cap bytes at dst; *produced = bytes written (also on failure: how far it got), *consumed =
+ * bytes of the stream including its Adler-32.  OMNI_OK | OMNI_ERR_INVALID (damaged stream, or more than cap bytes) | OMNI_ERR_UNSUPPORTED (the input ends
+ * inside the stream).  omni_png_checksums: CRC-32 (chunk check) and Adler-32 (zlib trailer) of a buffer, continuing from *crc32 / *adler32 (start: 0 / 1). */
+int omni_zlib_inflate(const void* src, size_t nbytes, void* dst, size_t cap, size_t* produced, size_t* consumed);
+int omni_png_checksums(const void* data, size_t nbytes, unsigned* crc32, unsigned* adler32);
 /* Reverse-Huber loss of supervision/direct.py:3-18 (train_erp_depth.py:267): *loss = mean_b(sum(loss * mask * weights)_b / sum(mask)_b)
  * with c = max|gt - pred| / 5 evaluated on the device.  `workspace` (omni_berhu_workspace_bytes(B) bytes) carries c and the
  * per-item counts to omni_berhu_grad_f32, which writes dloss/dpred * (*grad_out). */

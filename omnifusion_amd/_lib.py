@@ -36,7 +36,7 @@ EXPORTS = [
     "omni_stem_sh", "omni_stem_sh_f16x3", "omni_maxpool3x3s2_sh", "omni_upsample_bilinear_sh", "omni_add_hw_sh", "omni_add_period_sh", "omni_layernorm512_sh", "omni_attention_qkv_sh",
     "omni_conv2d_splitk_plan", "omni_conv2d_nhwc_f32_ws",
     "omni_masked_median_f32", "omni_depth_metrics_f32",
-    "omni_png_info", "omni_png_decode", "omni_png_decode_batch",
+    "omni_png_info", "omni_png_decode", "omni_png_decode_batch", "omni_zlib_inflate", "omni_png_checksums",
     "omni_preprocess_rgb_u8", "omni_preprocess_depth_u16", "omni_berhu_workspace_bytes", "omni_berhu_loss_f32", "omni_berhu_grad_f32",
     "omni_pointcloud_ply_f32",
 ]

@@ -96,7 +96,7 @@ def build(force=False, verbose=False, debug=False):
             if os.path.exists(lib):
                 os.remove(lib)
             raise RuntimeError("ISA check failed:\n  " + "\n  ".join(bad))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz"])   # zlib: inflate of omni_png.hip
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib
 
 

@@ -8,11 +8,10 @@
 //
 // PNG is lossless: every conforming decoder returns the same samples, so parity here is conformance to the PNG specification
 // (ISO/IEC 15948: chunk layout, zlib stream over the concatenated IDAT chunks, the five scan-line filters) plus OpenCV's documented
-// conversions listed above.  Inflate is zlib's (the image ships libz; the reference's OpenCV links the same library through libpng);
-// everything else — chunk walk, CRC check, un-filtering, sample conversion, the worker pool — is here.
+// conversions listed above.  Everything is here: chunk walk, CRC check, inflate (omni_inflate.h: rounds 4-5 called libz, which was 70 % of a panorama's decode time), un-filtering,
+// sample conversion, the worker pool.
 // Supported: colour types 0 (gray), 2 (RGB), 3 (palette), 4 (gray + alpha), 6 (RGB + alpha) at 8 bits, types 0 / 2 / 4 / 6 at 16 bits; no
 // interlacing (Adam7) and no 1/2/4-bit samples (OMNI_ERR_UNSUPPORTED; neither occurs in the dataset).
-#include <zlib.h>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +25,7 @@
 #include <thread>
 #include <vector>
 #include "omni_internal.h"
+#include "omni_inflate.h"
 
 namespace {
 
@@ -35,111 +35,190 @@ inline unsigned be32(const unsigned char* p) { return ((unsigned)p[0] << 24) | (
 
 int channels_of(int ctype) { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0; }
 
-// walks the chunks: fills `info`, the palette, and inflates the concatenated IDAT payloads into `raw` (filter byte + samples per scan line)
+constexpr size_t RAW_SLACK = 32;        // bytes behind the last scan line that the 4- / 16-byte accesses of the row kernels may read
+
+// walks the chunks: fills `info`, the palette, and inflates the zlib stream of the IDAT chunks into `raw` (filter byte + samples per scan line).
+// One IDAT: inflated where it lies; several (libpng writes 8-KiB chunks): their payloads are laid end to end in `zbuf` first.
 // (expect_w / expect_h > 0: the destination's size — a header that announces anything else is refused BEFORE a byte is allocated for it)
-int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsigned char>& raw, unsigned char (*pal)[3], int* npal, bool info_only,
-               int expect_w = 0, int expect_h = 0)
+int png_unpack(const unsigned char* d, size_t n, PngInfo& info, std::vector<unsigned char>& raw, std::vector<unsigned char>& zbuf, unsigned char (*pal)[3], int* npal,
+               bool info_only, int expect_w = 0, int expect_h = 0)
 {
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (n < 8 + 25 || memcmp(d, sig, 8) != 0) OMNI_FAIL(OMNI_ERR_INVALID, "png: not a PNG stream");
     size_t pos = 8;
-    bool have_ihdr = false, done = false, inflating = false;
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
+    bool have_ihdr = false, done = false;
     size_t rawsize = 0;
-    int rc = OMNI_OK;
+    const unsigned char* z0 = nullptr;                             // the first non-empty IDAT payload ...
+    size_t zn = 0, zparts = 0, ztotal = 0;                         // ... its length, the number of payloads, their total length
     while (pos + 12 <= n && !done) {
         const unsigned len = be32(d + pos);
         const unsigned char* type = d + pos + 4;
         const unsigned char* body = d + pos + 8;
-        if ((size_t)len > n - pos - 12) { rc = OMNI_ERR_INVALID; omni_set_error("png: truncated chunk"); break; }
-        if (be32(body + len) != (unsigned)crc32(crc32(0L, Z_NULL, 0), type, len + 4)) { rc = OMNI_ERR_INVALID; omni_set_error("png: chunk CRC mismatch"); break; }
+        if ((size_t)len > n - pos - 12) OMNI_FAIL(OMNI_ERR_INVALID, "png: truncated chunk");
+        if (be32(body + len) != omni_inflate::crc32_fast(0u, type, (size_t)len + 4)) OMNI_FAIL(OMNI_ERR_INVALID, "png: chunk CRC mismatch");
         if (!memcmp(type, "IHDR", 4)) {
-            if (have_ihdr) { rc = OMNI_ERR_INVALID; omni_set_error("png: a second IHDR chunk"); break; }
-            if (len != 13) { rc = OMNI_ERR_INVALID; omni_set_error("png: bad IHDR"); break; }
+            if (have_ihdr) OMNI_FAIL(OMNI_ERR_INVALID, "png: a second IHDR chunk");
+            if (len != 13) OMNI_FAIL(OMNI_ERR_INVALID, "png: bad IHDR");
             info.w = (int)be32(body); info.h = (int)be32(body + 4); info.depth = body[8]; info.ctype = body[9]; info.interlace = body[12];
             have_ihdr = true;
-            if (info.w <= 0 || info.h <= 0 || channels_of(info.ctype) == 0 || body[10] != 0 || body[11] != 0) { rc = OMNI_ERR_INVALID; omni_set_error("png: bad IHDR fields"); break; }
-            if (info_only) { done = true; break; }
-            if (info.interlace != 0) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: interlaced (Adam7) files are not supported"); break; }
-            if (!(info.depth == 8 || (info.depth == 16 && info.ctype != 3))) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: only 8- and 16-bit samples are supported"); break; }
+            if (info.w <= 0 || info.h <= 0 || channels_of(info.ctype) == 0 || body[10] != 0 || body[11] != 0) OMNI_FAIL(OMNI_ERR_INVALID, "png: bad IHDR fields");
+            if (info_only) return OMNI_OK;
+            if (info.interlace != 0) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: interlaced (Adam7) files are not supported");
+            if (!(info.depth == 8 || (info.depth == 16 && info.ctype != 3))) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: only 8- and 16-bit samples are supported");
             // the header is untrusted input: the sizes are checked (against the destination, and against 2 GiB in 64-bit arithmetic —
             // w, h < 2^31 and <= 8 bytes per pixel cannot wrap it) before anything is allocated for them
-            if ((expect_w > 0 && info.w != expect_w) || (expect_h > 0 && info.h != expect_h)) {
-                rc = OMNI_ERR_INVALID;
-                omni_set_error("png: the image is " + std::to_string(info.h) + " x " + std::to_string(info.w) + ", the destination " + std::to_string(expect_h) + " x " + std::to_string(expect_w));
-                break;
-            }
+            if ((expect_w > 0 && info.w != expect_w) || (expect_h > 0 && info.h != expect_h))
+                OMNI_FAIL(OMNI_ERR_INVALID, "png: the image is " + std::to_string(info.h) + " x " + std::to_string(info.w) + ", the destination " + std::to_string(expect_h) + " x " + std::to_string(expect_w));
             const unsigned long long stride = (unsigned long long)info.w * channels_of(info.ctype) * (info.depth / 8);
-            if (stride + 1 > 0x7fffffffull || (stride + 1) * (unsigned long long)info.h > 0x7fffffffull) { rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: image too large (2 GiB of samples or more)"); break; }
+            if (stride + 1 > 0x7fffffffull || (stride + 1) * (unsigned long long)info.h > 0x7fffffffull) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: image too large (2 GiB of samples or more)");
             rawsize = (size_t)((stride + 1) * (unsigned long long)info.h);
-            if (raw.size() < rawsize) raw.resize(rawsize);          // (grows only: the caller may keep it across images; inflate overwrites every byte it reports)
-            if (inflateInit(&zs) != Z_OK) { rc = OMNI_ERR_HIP; omni_set_error("png: inflateInit failed"); break; }
-            inflating = true;
-            zs.next_out = raw.data(); zs.avail_out = (uInt)rawsize;
+            if (raw.size() < rawsize + RAW_SLACK) raw.resize(rawsize + RAW_SLACK);   // (grows only: the caller keeps it across images; inflate writes every byte it reports)
         } else if (!have_ihdr) {
-            rc = OMNI_ERR_INVALID; omni_set_error("png: IHDR is not the first chunk"); break;
+            OMNI_FAIL(OMNI_ERR_INVALID, "png: IHDR is not the first chunk");
         } else if (!memcmp(type, "PLTE", 4)) {
-            if (len % 3 != 0 || len > 768) { rc = OMNI_ERR_INVALID; omni_set_error("png: bad PLTE"); break; }
+            if (len % 3 != 0 || len > 768) OMNI_FAIL(OMNI_ERR_INVALID, "png: bad PLTE");
             *npal = (int)(len / 3);
             memcpy(pal, body, len);
         } else if (!memcmp(type, "IDAT", 4)) {
-            if (len == 0) { pos += 12; continue; }                 // an empty IDAT is legal (cv2.imread reads such files): nothing to inflate
-            zs.next_in = const_cast<unsigned char*>(body); zs.avail_in = len;
-            const int zr = inflate(&zs, Z_NO_FLUSH);
-            if (zr != Z_OK && zr != Z_STREAM_END) { rc = OMNI_ERR_INVALID; omni_set_error("png: corrupt zlib stream"); break; }
-            if (zs.avail_in != 0 && zr != Z_STREAM_END) { rc = OMNI_ERR_INVALID; omni_set_error("png: more image data than the header announces"); break; }
+            if (len != 0) {                                        // an empty IDAT is legal (cv2.imread reads such files): nothing to inflate
+                if (zparts == 0) { z0 = body; zn = len; }
+                else {
+                    if (zparts == 1) { zbuf.clear(); zbuf.insert(zbuf.end(), z0, z0 + zn); }
+                    zbuf.insert(zbuf.end(), body, body + len);
+                }
+                ++zparts; ztotal += len;
+            }
         } else if (!memcmp(type, "IEND", 4)) {
             done = true;
         } else if (!(type[0] & 0x20)) {                            // an unknown CRITICAL chunk
-            rc = OMNI_ERR_UNSUPPORTED; omni_set_error("png: unknown critical chunk"); break;
+            OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: unknown critical chunk");
         }
         pos += 12 + (size_t)len;
     }
-    if (inflating) {
-        if (rc == OMNI_OK && zs.total_out != rawsize) { rc = OMNI_ERR_INVALID; omni_set_error("png: image data ends early"); }
-        inflateEnd(&zs);
-    }
-    if (rc == OMNI_OK && !have_ihdr) { rc = OMNI_ERR_INVALID; omni_set_error("png: no IHDR"); }
-    if (rc == OMNI_OK && !info_only && !done) { rc = OMNI_ERR_INVALID; omni_set_error("png: no IEND"); }
-    return rc;
+    if (!have_ihdr) OMNI_FAIL(OMNI_ERR_INVALID, "png: no IHDR");
+    if (!done) OMNI_FAIL(OMNI_ERR_INVALID, "png: no IEND");
+    const unsigned char* zp = zparts > 1 ? zbuf.data() : z0;
+    size_t produced = 0;
+    const int zr = zparts == 0 ? omni_inflate::INF_TRUNCATED : omni_inflate::zlib_decompress(zp, ztotal, raw.data(), rawsize, nullptr, &produced);
+    if (zr == omni_inflate::INF_OUTPUT_FULL) OMNI_FAIL(OMNI_ERR_INVALID, "png: more image data than the header announces");
+    if (zr == omni_inflate::INF_CORRUPT) OMNI_FAIL(OMNI_ERR_INVALID, "png: corrupt zlib stream");
+    if (produced != rawsize) OMNI_FAIL(OMNI_ERR_INVALID, "png: image data ends early");
+    // (INF_TRUNCATED with every sample present — a stream cut inside its Adler-32 trailer — is accepted, as libz's streaming inflate accepted it)
+    return OMNI_OK;
 }
 
+// ------------------------------------------------------------------ scan-line reconstruction (PNG spec 9.2), one row at a time
 inline int paeth(int a, int b, int c)
 {
     const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// in-place reconstruction of the scan lines (PNG spec 9.2): raw = h x (1 + stride); bpp = bytes per complete pixel
-int png_unfilter(std::vector<unsigned char>& raw, int h, size_t stride, int bpp)
+// x: the row's n bytes (in place), prev: the reconstructed row above (nullptr for the first row = a row of zeros), BPP bytes per complete pixel
+template <int BPP>
+bool unfilter_row(int ft, unsigned char* x, const unsigned char* prev, size_t n)
 {
-    const unsigned char* prev = nullptr;
-    for (int y = 0; y < h; ++y) {
-        unsigned char* row = raw.data() + (size_t)y * (stride + 1);
-        const int ft = row[0];
-        unsigned char* x = row + 1;
-        switch (ft) {
-        case 0: break;
-        case 1: for (size_t i = bpp; i < stride; ++i) x[i] = (unsigned char)(x[i] + x[i - bpp]); break;
-        case 2: if (prev) for (size_t i = 0; i < stride; ++i) x[i] = (unsigned char)(x[i] + prev[i]); break;
-        case 3:
-            for (size_t i = 0; i < stride; ++i) {
-                const int a = i >= (size_t)bpp ? x[i - bpp] : 0, b = prev ? prev[i] : 0;
-                x[i] = (unsigned char)(x[i] + ((a + b) >> 1));
-            }
-            break;
-        case 4:
-            for (size_t i = 0; i < stride; ++i) {
-                const int a = i >= (size_t)bpp ? x[i - bpp] : 0, b = prev ? prev[i] : 0, c = (prev && i >= (size_t)bpp) ? prev[i - bpp] : 0;
-                x[i] = (unsigned char)(x[i] + paeth(a, b, c));
-            }
-            break;
-        default: OMNI_FAIL(OMNI_ERR_INVALID, "png: unknown filter type");
-        }
-        prev = x;
+    switch (ft) {
+    case 0: return true;
+    case 1: for (size_t i = BPP; i < n; ++i) x[i] = (unsigned char)(x[i] + x[i - BPP]); return true;
+    case 2: if (prev) for (size_t i = 0; i < n; ++i) x[i] = (unsigned char)(x[i] + prev[i]); return true;
+    case 3:
+        if (prev) {
+            for (size_t i = 0; i < (size_t)BPP && i < n; ++i) x[i] = (unsigned char)(x[i] + (prev[i] >> 1));
+            for (size_t i = BPP; i < n; ++i) x[i] = (unsigned char)(x[i] + ((x[i - BPP] + prev[i]) >> 1));
+        } else
+            for (size_t i = BPP; i < n; ++i) x[i] = (unsigned char)(x[i] + (x[i - BPP] >> 1));
+        return true;
+    case 4:
+        if (prev) {
+            for (size_t i = 0; i < (size_t)BPP && i < n; ++i) x[i] = (unsigned char)(x[i] + prev[i]);                      // paeth(0, b, 0) = b
+            for (size_t i = BPP; i < n; ++i) x[i] = (unsigned char)(x[i] + paeth(x[i - BPP], prev[i], prev[i - BPP]));
+        } else
+            for (size_t i = BPP; i < n; ++i) x[i] = (unsigned char)(x[i] + x[i - BPP]);                                       // paeth(a, 0, 0) = a
+        return true;
+    default: return false;
     }
-    return OMNI_OK;
+}
+
+// 8-bit RGB (3 bytes per pixel, the panoramas): the three filters with a serial dependence on the pixel to the left, one PIXEL per step in a vector
+// register instead of one byte (4-byte loads — the 4th byte belongs to the next pixel and is ignored; 2 + 1-byte stores: the row is reconstructed in
+// place and the next pixel's raw byte must survive).  prev != nullptr; the first pixel (no left neighbour) and the last (its 4-byte load would leave
+// the row) go through the byte loops.
+inline __m128i load4(const unsigned char* p) { int v; memcpy(&v, p, 4); return _mm_cvtsi32_si128(v); }
+inline void store3(unsigned char* p, __m128i v) { const unsigned r = (unsigned)_mm_cvtsi128_si32(v); const unsigned short lo = (unsigned short)r; memcpy(p, &lo, 2); p[2] = (unsigned char)(r >> 16); }
+
+inline void sub3_row(unsigned char* x, size_t n)
+{
+    if (n < 9) { unfilter_row<3>(1, x, nullptr, n); return; }
+    __m128i a = load4(x);
+    size_t i = 3;
+    for (; i + 3 < n; i += 3) { a = _mm_add_epi8(a, load4(x + i)); store3(x + i, a); }
+    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + x[i - 3]);
+}
+
+inline void avg3_row(unsigned char* x, const unsigned char* prev, size_t n)
+{
+    if (n < 9) { unfilter_row<3>(3, x, prev, n); return; }
+    for (size_t i = 0; i < 3; ++i) x[i] = (unsigned char)(x[i] + (prev[i] >> 1));
+    __m128i a = load4(x);
+    const __m128i one = _mm_set1_epi8(1);
+    size_t i = 3;
+    for (; i + 3 < n; i += 3) {
+        const __m128i b = load4(prev + i);
+        const __m128i avg = _mm_sub_epi8(_mm_avg_epu8(a, b), _mm_and_si128(_mm_xor_si128(a, b), one));      // pavgb rounds up: floor((a + b) / 2) = it - ((a ^ b) & 1)
+        a = _mm_add_epi8(load4(x + i), avg);
+        store3(x + i, a);
+    }
+    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + ((x[i - 3] + prev[i]) >> 1));
+}
+
+__attribute__((target("ssse3"))) inline void paeth3_row_ssse3(unsigned char* x, const unsigned char* prev, size_t n)
+{
+    for (size_t i = 0; i < 3; ++i) x[i] = (unsigned char)(x[i] + prev[i]);
+    const __m128i zero = _mm_setzero_si128();
+    __m128i a = _mm_unpacklo_epi8(load4(x), zero), c = _mm_unpacklo_epi8(load4(prev), zero);           // 16-bit lanes
+    size_t i = 3;
+    for (; i + 3 < n; i += 3) {
+        const __m128i b = _mm_unpacklo_epi8(load4(prev + i), zero);
+        const __m128i dbc = _mm_sub_epi16(b, c), dac = _mm_sub_epi16(a, c);                                // p - a = b - c, p - b = a - c, p - c = their sum
+        const __m128i pa = _mm_abs_epi16(dbc), pb = _mm_abs_epi16(dac), pc = _mm_abs_epi16(_mm_add_epi16(dbc, dac));
+        const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+        const __m128i ma = _mm_cmpeq_epi16(smallest, pa), mb = _mm_cmpeq_epi16(smallest, pb);             // ties: a, then b, then c (the spec's order)
+        const __m128i bc = _mm_or_si128(_mm_and_si128(mb, b), _mm_andnot_si128(mb, c));
+        const __m128i pred = _mm_or_si128(_mm_and_si128(ma, a), _mm_andnot_si128(ma, bc));
+        a = _mm_and_si128(_mm_add_epi16(pred, _mm_unpacklo_epi8(load4(x + i), zero)), _mm_set1_epi16(0xff));
+        c = b;
+        store3(x + i, _mm_packus_epi16(a, a));
+    }
+    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + paeth(x[i - 3], prev[i], prev[i - 3]));
+}
+
+// RGB -> BGR, 8 bits: five pixels per 16-byte load / store (the 16th byte is rewritten by the next store; the loop ends while 6 pixels remain)
+__attribute__((target("ssse3"))) inline void rgb_to_bgr_row_ssse3(const unsigned char* s, unsigned char* q, int W)
+{
+    const __m128i sh = _mm_setr_epi8(2, 1, 0, 5, 4, 3, 8, 7, 6, 11, 10, 9, 14, 13, 12, 15);
+    int x = 0;
+    for (; x + 6 <= W; x += 5, s += 15, q += 15) _mm_storeu_si128((__m128i*)q, _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)s), sh));
+    for (; x < W; ++x, s += 3, q += 3) { const unsigned char r = s[0], g = s[1], b = s[2]; q[0] = b; q[1] = g; q[2] = r; }
+}
+
+bool cpu_has_ssse3() { static const bool v = __builtin_cpu_supports("ssse3"); return v; }
+
+bool unfilter_any(int bpp, int ft, unsigned char* x, const unsigned char* prev, size_t n)
+{
+    switch (bpp) {
+    case 1: return unfilter_row<1>(ft, x, prev, n);
+    case 2: return unfilter_row<2>(ft, x, prev, n);
+    case 3:
+        if (ft == 1) { sub3_row(x, n); return true; }
+        if (prev && ft == 3) { avg3_row(x, prev, n); return true; }
+        if (prev && ft == 4 && n >= 9 && cpu_has_ssse3()) { paeth3_row_ssse3(x, prev, n); return true; }
+        return unfilter_row<3>(ft, x, prev, n);
+    case 4: return unfilter_row<4>(ft, x, prev, n);
+    case 6: return unfilter_row<6>(ft, x, prev, n);
+    case 8: return unfilter_row<8>(ft, x, prev, n);
+    default: return false;
+    }
 }
 
 // kind 0: cv2.imread(path) -> uint8 BGR [H,W,3];  kind 1: cv2.imread(path, -1) of a single-channel file -> uint8 / uint16 [H,W] in host byte order
@@ -151,26 +230,32 @@ int png_decode_body(const unsigned char* d, size_t n, void* dst, int H, int W, i
     // is an mmap + page faults + a zero fill each time, and with 64 decoder threads the kernel's address-space lock serialises them (round 5: 216 MB/s
     // per thread on 8 threads, 80 MB/s on 64)
     struct Lease {
-        std::vector<unsigned char> buf;
-        Lease() { std::lock_guard<std::mutex> lk(mu()); if (!pool().empty()) { buf.swap(pool().back()); pool().pop_back(); } }
-        ~Lease() { std::lock_guard<std::mutex> lk(mu()); if (pool().size() < 256 && buf.capacity() <= (64u << 20)) pool().emplace_back(std::move(buf)); }
+        std::vector<unsigned char> buf, zbuf;
+        Lease() { std::lock_guard<std::mutex> lk(mu()); if (!pool().empty()) { buf.swap(pool().back().first); zbuf.swap(pool().back().second); pool().pop_back(); } }
+        ~Lease() { std::lock_guard<std::mutex> lk(mu()); if (pool().size() < 256 && buf.capacity() <= (64u << 20) && zbuf.capacity() <= (64u << 20)) pool().emplace_back(std::move(buf), std::move(zbuf)); }
         static std::mutex& mu() { static std::mutex m; return m; }
-        static std::vector<std::vector<unsigned char>>& pool() { static std::vector<std::vector<unsigned char>> p; return p; }
+        static std::vector<std::pair<std::vector<unsigned char>, std::vector<unsigned char>>>& pool() { static std::vector<std::pair<std::vector<unsigned char>, std::vector<unsigned char>>> p; return p; }
     } lease;
     std::vector<unsigned char>& raw = lease.buf;
     unsigned char pal[256][3];
     int npal = 0;
-    int rc = png_unpack(d, n, info, raw, pal, &npal, false, W, H);
+    int rc = png_unpack(d, n, info, raw, lease.zbuf, pal, &npal, false, W, H);
     if (rc != OMNI_OK) return rc;
     const int ch = channels_of(info.ctype), bs = info.depth / 8, bpp = ch * bs;
     const size_t stride = (size_t)W * bpp;
-    rc = png_unfilter(raw, H, stride, bpp);
-    if (rc != OMNI_OK) return rc;
-    if (kind == 0) {
-        unsigned char* o = (unsigned char*)dst;
-        for (int y = 0; y < H; ++y) {
-            const unsigned char* s = raw.data() + (size_t)y * (stride + 1) + 1;
-            unsigned char* q = o + (size_t)y * W * 3;
+    if (kind == 1 && (ch != 1 || info.ctype == 3)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: the unchanged (-1) read is implemented for single-channel gray files (depth maps)");
+    if (elem_bytes) *elem_bytes = kind == 0 ? 1 : bs;
+    const bool rgb8 = info.ctype == 2 && bs == 1 && cpu_has_ssse3();
+    const unsigned char* prev = nullptr;
+    // a row is reconstructed and converted while it sits in the L1 cache (one pass over the image instead of two)
+    for (int y = 0; y < H; ++y) {
+        unsigned char* row = raw.data() + (size_t)y * (stride + 1);
+        unsigned char* s = row + 1;
+        if (!unfilter_any(bpp, row[0], s, prev, stride)) OMNI_FAIL(OMNI_ERR_INVALID, "png: unknown filter type");
+        prev = s;
+        if (kind == 0) {
+            unsigned char* q = (unsigned char*)dst + (size_t)y * W * 3;
+            if (rgb8) { rgb_to_bgr_row_ssse3(s, q, W); continue; }
             for (int x = 0; x < W; ++x, s += bpp, q += 3) {
                 unsigned char r, g, b;                              // 16-bit samples: the high byte (OpenCV's IMREAD_COLOR scales 16 -> 8 bits by >> 8)
                 if (info.ctype == 3) { const int i = s[0]; if (i >= npal) OMNI_FAIL(OMNI_ERR_INVALID, "png: palette index out of range"); r = pal[i][0]; g = pal[i][1]; b = pal[i][2]; }
@@ -178,16 +263,9 @@ int png_decode_body(const unsigned char* d, size_t n, void* dst, int H, int W, i
                 else { r = s[0]; g = s[bs]; b = s[2 * bs]; }
                 q[0] = b; q[1] = g; q[2] = r;
             }
-        }
-        if (elem_bytes) *elem_bytes = 1;
-        return OMNI_OK;
-    }
-    if (ch != 1 || info.ctype == 3) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "png: the unchanged (-1) read is implemented for single-channel gray files (depth maps)");
-    if (elem_bytes) *elem_bytes = bs;
-    for (int y = 0; y < H; ++y) {
-        const unsigned char* s = raw.data() + (size_t)y * (stride + 1) + 1;
-        if (bs == 1) memcpy((unsigned char*)dst + (size_t)y * W, s, W);
-        else {
+        } else if (bs == 1) {
+            memcpy((unsigned char*)dst + (size_t)y * W, s, W);
+        } else {
             unsigned short* q = (unsigned short*)dst + (size_t)y * W;
             for (int x = 0; x < W; ++x) q[x] = (unsigned short)((s[2 * x] << 8) | s[2 * x + 1]);      // network (big-endian) -> host order
         }
@@ -215,7 +293,8 @@ extern "C" int omni_png_info(const void* data, size_t nbytes, int* width, int* h
     std::vector<unsigned char> raw;
     int npal = 0;
     int rc;
-    try { rc = png_unpack((const unsigned char*)data, nbytes, info, raw, nullptr, &npal, true); }
+    std::vector<unsigned char> zbuf;
+    try { rc = png_unpack((const unsigned char*)data, nbytes, info, raw, zbuf, nullptr, &npal, true); }
     catch (const std::exception& e) { OMNI_FAIL(OMNI_ERR_INVALID, std::string("png: ") + e.what()); }
     if (rc != OMNI_OK) return rc;
     if (width) *width = info.w;
@@ -230,6 +309,27 @@ extern "C" int omni_png_decode(const void* data, size_t nbytes, void* dst, int H
     if (!data || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_png_decode: null buffer");
     if (kind != 0 && kind != 1) OMNI_FAIL(OMNI_ERR_INVALID, "omni_png_decode: kind must be 0 (BGR uint8, cv2.imread) or 1 (unchanged gray, cv2.imread(path, -1))");
     return png_decode((const unsigned char*)data, nbytes, dst, H, W, kind, nullptr);
+}
+
+extern "C" int omni_zlib_inflate(const void* src, size_t nbytes, void* dst, size_t cap, size_t* produced, size_t* consumed)
+{
+    if (produced) *produced = 0;
+    if (consumed) *consumed = 0;
+    if (!src || (!dst && cap)) OMNI_FAIL(OMNI_ERR_INVALID, "omni_zlib_inflate: null buffer");
+    unsigned char none = 0;
+    const int r = omni_inflate::zlib_decompress((const unsigned char*)src, nbytes, dst ? (unsigned char*)dst : &none, cap, consumed, produced);
+    if (r == omni_inflate::INF_OK) return OMNI_OK;
+    if (r == omni_inflate::INF_TRUNCATED) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_zlib_inflate: the input ends inside the stream");
+    if (r == omni_inflate::INF_OUTPUT_FULL) OMNI_FAIL(OMNI_ERR_INVALID, "omni_zlib_inflate: the stream holds more than the destination");
+    OMNI_FAIL(OMNI_ERR_INVALID, "omni_zlib_inflate: corrupt stream");
+}
+
+extern "C" int omni_png_checksums(const void* data, size_t nbytes, unsigned* crc32, unsigned* adler32)
+{
+    if (!data && nbytes) OMNI_FAIL(OMNI_ERR_INVALID, "omni_png_checksums: null buffer");
+    if (crc32) *crc32 = omni_inflate::crc32_fast(*crc32, (const unsigned char*)data, nbytes);
+    if (adler32) *adler32 = omni_inflate::adler32(*adler32, (const unsigned char*)data, nbytes);
+    return OMNI_OK;
 }
 
 // A process-wide pool of decoder threads, started on first use: a batch call used to create (and join) its own std::threads — with several batch

@@ -179,3 +179,163 @@ def test_png_batches_abandoned_iterator_and_buffer_recycling():
         pb.recycle(b)                                                             # done with it at once: later batches reuse the buffers
     assert np.array_equal(np.concatenate(seen), np.stack([f[:, :, ::-1] for f in frames]))
     assert len(ptrs) < len(seen)
+
+
+# ------------------------------------------------------------------ round 5: the decoder's own inflate / checksums (csrc/omni_inflate.h) against Python's zlib
+def _inflate(z, cap):
+    """omni_zlib_inflate -> (status, produced bytes, consumed)"""
+    import ctypes
+    from omnifusion_amd import _lib as L
+    lib = L.load()
+    out = np.empty(max(cap, 1), np.uint8)
+    prod, used = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = lib.omni_zlib_inflate(ctypes.c_char_p(z), ctypes.c_size_t(len(z)), ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(cap), ctypes.byref(prod), ctypes.byref(used))
+    return rc, out[:prod.value].tobytes(), used.value
+
+
+def _zlib_says(z, cap):
+    try:
+        do = zlib.decompressobj()
+        o = do.decompress(z, cap + 1)
+        if len(o) > cap:
+            return "full", None
+        return ("ok", o) if do.eof else ("short", o)
+    except zlib.error:
+        return "bad", None
+
+
+def _payloads():
+    r = np.random.default_rng(11)
+    yield b""
+    yield b"a"
+    yield b"abc" * 1000                                                            # overlapping matches (distance 3), then long ones
+    yield bytes(100000)                                                            # distance 1, length 258 runs
+    yield r.integers(0, 256, 70000, dtype=np.uint8).tobytes()                      # incompressible: stored blocks at level 0, literals otherwise
+    yield r.integers(0, 4, 200000, dtype=np.uint8).tobytes()                       # tiny alphabet: 2-bit codes, two literals per table look-up
+    yield r.integers(0, 256, 1000, dtype=np.uint8).tobytes() * 200                 # distance 1000 matches
+    yield np.cumsum(r.integers(-3, 4, 300000)).astype(np.uint8).tobytes()          # image-like residuals: short matches, every code length
+    yield bytes(r.choice([0, 1, 2, 255], 150000, p=[.9, .05, .03, .02]).astype(np.uint8))   # skewed: 1-bit codes and 12+-bit ones (second-level tables)
+    yield bytes(range(256)) * 3 + r.integers(0, 256, 40000, dtype=np.uint8).tobytes()[:30000] + bytes(range(255, -1, -1))
+    for n in (1, 2, 3, 15, 16, 17, 255, 256, 257, 258, 259, 300, 32767, 32768, 32769, 65536):
+        yield r.integers(0, 8, n, dtype=np.uint8).tobytes()
+
+
+def test_inflate_equals_zlib_on_valid_streams():
+    """every block type (stored / fixed / dynamic via the strategies), window sizes, output exactly full, one byte short, trailing bytes after the stream"""
+    n = 0
+    for d in _payloads():
+        for lvl in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                for wbits in (15, 9):
+                    c = zlib.compressobj(lvl, zlib.DEFLATED, wbits, 8, strat)
+                    z = c.compress(d) + c.flush()
+                    rc, o, used = _inflate(z, len(d))
+                    assert rc == 0 and o == d and used == len(z), (len(d), lvl, strat, wbits, rc)
+                    rc, o, used = _inflate(z + b"trailing", len(d) + 7)
+                    assert rc == 0 and o == d and used == len(z)
+                    if d:
+                        rc, o, _ = _inflate(z, len(d) - 1)
+                        assert rc != 0 and o == d[:len(o)]
+                    n += 1
+    assert n > 800
+    # a stream of many blocks with empty stored blocks between them (Z_SYNC_FLUSH)
+    r = np.random.default_rng(12)
+    c, z, parts = zlib.compressobj(6), b"", [r.integers(0, 16, 5000, dtype=np.uint8).tobytes() for _ in range(20)]
+    for p in parts:
+        z += c.compress(p) + c.flush(zlib.Z_SYNC_FLUSH)
+    z += c.flush()
+    rc, o, _ = _inflate(z, 100000)
+    assert rc == 0 and o == b"".join(parts)
+
+
+def test_inflate_refuses_what_zlib_refuses():
+    """truncated at every byte of the first 200 and a sample beyond, the last 12 bytes one by one; 1-3 flipped bits; random bytes behind a valid
+    header: accepted exactly where Python's zlib accepts, with the same bytes, and whatever was produced before a failure is a prefix of the truth"""
+    r = np.random.default_rng(13)
+    d = np.cumsum(r.integers(-2, 3, 60000)).astype(np.uint8).tobytes()
+    for lvl in (1, 6):
+        z = zlib.compress(d, lvl)
+        for cut in list(range(0, 200)) + list(range(200, len(z), 97)) + [len(z) - k for k in range(1, 12)]:
+            rc, o, _ = _inflate(z[:cut], len(d))
+            assert rc != 0 and o == d[:len(o)], cut
+            assert _zlib_says(z[:cut], len(d))[0] in ("short", "bad")
+    both_ok = 0
+    for trial in range(1500):
+        z = bytearray(zlib.compress(d[:int(r.integers(100, 20000))], int(r.choice([1, 6, 9]))))
+        cap = len(zlib.decompress(bytes(z)))
+        for _ in range(int(r.integers(1, 4))):
+            z[int(r.integers(0, len(z)))] ^= 1 << int(r.integers(0, 8))
+        rc, o, _ = _inflate(bytes(z), cap)
+        kind, ref = _zlib_says(bytes(z), cap)
+        assert (rc == 0) == (kind == "ok"), (trial, rc, kind)
+        if rc == 0:
+            assert o == ref
+            both_ok += 1
+    for trial in range(1500):
+        z = bytes([0x78, 0x9c]) + r.integers(0, 256, int(r.integers(1, 400)), dtype=np.uint8).tobytes()
+        rc, o, _ = _inflate(z, 5000)
+        assert (rc == 0) == (_zlib_says(z, 5000)[0] == "ok"), trial
+    # header checks: method, window, check bits, preset dictionary
+    good = zlib.compress(b"hello hello hello")
+    for bad in (bytes([0x79]) + good[1:], bytes([0x88]) + good[1:], bytes([good[0], good[1] ^ 1]) + good[2:], bytes([0x78, 0xbb]) + good[2:]):
+        assert _inflate(bad, 100)[0] != 0
+
+
+def test_checksums_equal_zlib():
+    import ctypes
+    from omnifusion_amd import _lib as L
+    lib = L.load()
+    r = np.random.default_rng(14)
+
+    def both(b, crc0=0, adler0=1):
+        c, a = ctypes.c_uint(crc0), ctypes.c_uint(adler0)
+        assert lib.omni_png_checksums(ctypes.c_char_p(b), ctypes.c_size_t(len(b)), ctypes.byref(c), ctypes.byref(a)) == 0
+        return c.value, a.value
+    for n in list(range(0, 200)) + [255, 256, 1000, 4099, 5551, 5552, 5553, 65536, 1572864 + 512]:
+        b = r.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert both(b) == (zlib.crc32(b), zlib.adler32(b)), n
+        assert both(b, 0x12345678, 0x00c0ffee) == (zlib.crc32(b, 0x12345678), zlib.adler32(b, 0x00c0ffee)), n
+    b = bytes([255]) * (1 << 21)                                                   # the largest sums: no 32-bit overflow between the modulo steps
+    assert both(b) == (zlib.crc32(b), zlib.adler32(b))
+
+
+@pytest.mark.parametrize("W", [1, 2, 3, 4, 7, 64, 1024])
+def test_rgb8_row_kernels_every_filter_on_every_row_position(W):
+    """the 8-bit RGB row kernels (one pixel per vector step) at widths below and above their minimum, every filter type on the first row (no row
+    above) and below it, smooth content (Paeth ties, all three outcomes) and noise"""
+    H = 10
+    yy, xx = np.mgrid[0:H, 0:W]
+    smooth = np.stack([(3 * xx + 5 * yy) % 256, (250 - 2 * xx + yy) % 256, (xx * yy) % 256], axis=2).astype(np.uint8)
+    noise = RNG.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    for a in (smooth, noise, np.zeros_like(noise), np.full_like(noise, 255)):
+        for rot in range(5):
+            filters = tuple((rot + k) % 5 for k in range(5))
+            assert np.array_equal(png.imread(encode_png(a, 2, 8, filters=filters, idat=2)), a[:, :, ::-1]), (W, rot)
+
+
+def test_many_small_idat_chunks_and_empty_ones():
+    """libpng writes 8-KiB IDAT chunks; here the stream is cut into 1-byte chunks with empty ones between them"""
+    a = RNG.integers(0, 256, (12, 17, 3), dtype=np.uint8)
+    one = encode_png(a, 2, 8, idat=1)
+    pos, z = 8, b""
+    while pos < len(one):
+        ln = struct.unpack(">I", one[pos:pos + 4])[0]
+        if one[pos + 4:pos + 8] == b"IDAT":
+            z += one[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    f = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", 17, 12, 8, 2, 0, 0, 0))
+    for k in range(len(z)):
+        f += _chunk(b"IDAT", z[k:k + 1]) + (_chunk(b"IDAT", b"") if k % 50 == 0 else b"")
+    f += _chunk(b"IEND", b"")
+    assert np.array_equal(png.imread(f), a[:, :, ::-1])
+    # a stream cut inside its Adler-32 trailer still carries every sample (libz's streaming inflate, and libpng with it, reads such files)
+    cut = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", 17, 12, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", z[:-2]) + _chunk(b"IEND", b"")
+    assert np.array_equal(png.imread(cut), a[:, :, ::-1])
+    # ... a wrong trailer is a damaged file
+    wrong = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", 17, 12, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", z[:-1] + bytes([z[-1] ^ 1])) + _chunk(b"IEND", b"")
+    with pytest.raises(ValueError, match="corrupt"):
+        png.imread(wrong)
+    # ... and so is a stream that holds more rows than the header announces
+    more = zlib.compress(zlib.decompress(z) + bytes(1 + 17 * 3))
+    with pytest.raises(ValueError, match="more image data"):
+        png.imread(b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", 17, 12, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", more) + _chunk(b"IEND", b""))

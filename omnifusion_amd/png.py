@@ -1,5 +1,5 @@
 """PNG decoding for the host input pipeline — the two `cv2.imread` calls of /root/reference/dataset_loader_stanford.py (:85 RGB panorama,
-:96 16-bit depth map) on a pool of host threads, straight into pinned memory (csrc/omni_png.hip; inflate is zlib's, the rest is ours).
+:96 16-bit depth map) on a pool of host threads, straight into pinned memory (csrc/omni_png.hip, csrc/omni_inflate.h: chunk walk, checksums, inflate, scan-line reconstruction — no third-party code on the path).
 
     rgb_u8  = imread(path)                 # uint8 [H,W,3], B G R order          == cv2.imread(path)
     depth   = imread(path, unchanged=True) # uint16 [H,W] (or uint8)             == cv2.imread(path, -1) of a gray file

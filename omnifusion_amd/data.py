@@ -120,7 +120,10 @@ class DeviceFeeder:
             s["pin"].numpy()[:a.shape[0]] = a                          # host memcpy into pinned memory (the worker's hand-over)
             src = s["pin"][:a.shape[0]]
         if s["free"] is not None:
-            self.side.wait_event(s["free"])                            # the consumer's preprocess has read this slot's device frame
+            # the consumer's preprocess has read this slot's device frame — waited for on the HOST (the event is `depth` batches old: it returns at
+            # once): a stream-side wait in front of the asynchronous copy makes the runtime hold the copy back (round 5, tools/feed_ab.py: 3593-3893
+            # panoramas/s, jittery, with 4 hardware queues and 2650 with 8, against 3904-3966 this way; the GPU-side cost of feeding is 1 %)
+            s["free"].synchronize()
         with torch.cuda.stream(self.side):
             s["dev"][:src.shape[0]].copy_(src, non_blocking=True)      # async H2D on the side stream
             s["ready"].record(self.side)

@@ -140,57 +140,71 @@ bool unfilter_row(int ft, unsigned char* x, const unsigned char* prev, size_t n)
     }
 }
 
-// 8-bit RGB (3 bytes per pixel, the panoramas): the three filters with a serial dependence on the pixel to the left, one PIXEL per step in a vector
-// register instead of one byte (4-byte loads — the 4th byte belongs to the next pixel and is ignored; 2 + 1-byte stores: the row is reconstructed in
-// place and the next pixel's raw byte must survive).  prev != nullptr; the first pixel (no left neighbour) and the last (its 4-byte load would leave
-// the row) go through the byte loops.
-inline __m128i load4(const unsigned char* p) { int v; memcpy(&v, p, 4); return _mm_cvtsi32_si128(v); }
-inline void store3(unsigned char* p, __m128i v) { const unsigned r = (unsigned)_mm_cvtsi128_si32(v); const unsigned short lo = (unsigned short)r; memcpy(p, &lo, 2); p[2] = (unsigned char)(r >> 16); }
+// The three filters with a serial dependence on the pixel to the left (Sub, Average, Paeth), one PIXEL per step in a vector register instead of one
+// byte: 8-byte loads (pixels have 1-8 bytes; the bytes behind the pixel belong to its right neighbours and are ignored), BPP-byte stores (the row is
+// reconstructed in place and the neighbours' raw bytes must survive).  prev != nullptr for Average / Paeth; the first pixel (no left neighbour) and the
+// last ones (their 8-byte load would leave the row) go through the byte loops.  8-bit RGB panoramas: 3 bytes per pixel; 16-bit depth maps: 2.
+inline __m128i load8(const unsigned char* p) { long long v; memcpy(&v, p, 8); return _mm_cvtsi64_si128(v); }
+template <int BPP> inline void store_px(unsigned char* p, __m128i v) { const long long r = _mm_cvtsi128_si64(v); memcpy(p, &r, BPP); }
 
-inline void sub3_row(unsigned char* x, size_t n)
+template <int BPP>
+inline void sub_row_v(unsigned char* x, size_t n)
 {
-    if (n < 9) { unfilter_row<3>(1, x, nullptr, n); return; }
-    __m128i a = load4(x);
-    size_t i = 3;
-    for (; i + 3 < n; i += 3) { a = _mm_add_epi8(a, load4(x + i)); store3(x + i, a); }
-    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + x[i - 3]);
+    if (n < 16) { unfilter_row<BPP>(1, x, nullptr, n); return; }
+    __m128i a = load8(x);
+    size_t i = BPP;
+    for (; i + 8 <= n; i += BPP) { a = _mm_add_epi8(a, load8(x + i)); store_px<BPP>(x + i, a); }
+    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + x[i - BPP]);
 }
 
-inline void avg3_row(unsigned char* x, const unsigned char* prev, size_t n)
+template <int BPP>
+inline void avg_row_v(unsigned char* x, const unsigned char* prev, size_t n)
 {
-    if (n < 9) { unfilter_row<3>(3, x, prev, n); return; }
-    for (size_t i = 0; i < 3; ++i) x[i] = (unsigned char)(x[i] + (prev[i] >> 1));
-    __m128i a = load4(x);
+    if (n < 16) { unfilter_row<BPP>(3, x, prev, n); return; }
+    for (size_t i = 0; i < (size_t)BPP; ++i) x[i] = (unsigned char)(x[i] + (prev[i] >> 1));
+    __m128i a = load8(x);
     const __m128i one = _mm_set1_epi8(1);
-    size_t i = 3;
-    for (; i + 3 < n; i += 3) {
-        const __m128i b = load4(prev + i);
+    size_t i = BPP;
+    for (; i + 8 <= n; i += BPP) {
+        const __m128i b = load8(prev + i);
         const __m128i avg = _mm_sub_epi8(_mm_avg_epu8(a, b), _mm_and_si128(_mm_xor_si128(a, b), one));      // pavgb rounds up: floor((a + b) / 2) = it - ((a ^ b) & 1)
-        a = _mm_add_epi8(load4(x + i), avg);
-        store3(x + i, a);
+        a = _mm_add_epi8(load8(x + i), avg);
+        store_px<BPP>(x + i, a);
     }
-    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + ((x[i - 3] + prev[i]) >> 1));
+    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + ((x[i - BPP] + prev[i]) >> 1));
 }
 
-__attribute__((target("ssse3"))) inline void paeth3_row_ssse3(unsigned char* x, const unsigned char* prev, size_t n)
+template <int BPP>
+__attribute__((target("ssse3"))) inline void paeth_row_v(unsigned char* x, const unsigned char* prev, size_t n)
 {
-    for (size_t i = 0; i < 3; ++i) x[i] = (unsigned char)(x[i] + prev[i]);
-    const __m128i zero = _mm_setzero_si128();
-    __m128i a = _mm_unpacklo_epi8(load4(x), zero), c = _mm_unpacklo_epi8(load4(prev), zero);           // 16-bit lanes
-    size_t i = 3;
-    for (; i + 3 < n; i += 3) {
-        const __m128i b = _mm_unpacklo_epi8(load4(prev + i), zero);
+    for (size_t i = 0; i < (size_t)BPP; ++i) x[i] = (unsigned char)(x[i] + prev[i]);
+    const __m128i zero = _mm_setzero_si128(), low = _mm_set1_epi16(0xff);
+    __m128i a = _mm_unpacklo_epi8(load8(x), zero), c = _mm_unpacklo_epi8(load8(prev), zero);           // 16-bit lanes
+    size_t i = BPP;
+    for (; i + 8 <= n; i += BPP) {
+        const __m128i b = _mm_unpacklo_epi8(load8(prev + i), zero);
         const __m128i dbc = _mm_sub_epi16(b, c), dac = _mm_sub_epi16(a, c);                                // p - a = b - c, p - b = a - c, p - c = their sum
         const __m128i pa = _mm_abs_epi16(dbc), pb = _mm_abs_epi16(dac), pc = _mm_abs_epi16(_mm_add_epi16(dbc, dac));
         const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
         const __m128i ma = _mm_cmpeq_epi16(smallest, pa), mb = _mm_cmpeq_epi16(smallest, pb);             // ties: a, then b, then c (the spec's order)
         const __m128i bc = _mm_or_si128(_mm_and_si128(mb, b), _mm_andnot_si128(mb, c));
         const __m128i pred = _mm_or_si128(_mm_and_si128(ma, a), _mm_andnot_si128(ma, bc));
-        a = _mm_and_si128(_mm_add_epi16(pred, _mm_unpacklo_epi8(load4(x + i), zero)), _mm_set1_epi16(0xff));
+        a = _mm_and_si128(_mm_add_epi16(pred, _mm_unpacklo_epi8(load8(x + i), zero)), low);
         c = b;
-        store3(x + i, _mm_packus_epi16(a, a));
+        store_px<BPP>(x + i, _mm_packus_epi16(a, a));
     }
-    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + paeth(x[i - 3], prev[i], prev[i - 3]));
+    for (; i < n; ++i) x[i] = (unsigned char)(x[i] + paeth(x[i - BPP], prev[i], prev[i - BPP]));
+}
+
+bool cpu_has_ssse3() { static const bool v = __builtin_cpu_supports("ssse3"); return v; }
+
+template <int BPP>
+bool unfilter_px(int ft, unsigned char* x, const unsigned char* prev, size_t n)
+{
+    if (ft == 1) { sub_row_v<BPP>(x, n); return true; }
+    if (prev && ft == 3) { avg_row_v<BPP>(x, prev, n); return true; }
+    if (prev && ft == 4 && n >= 16 && cpu_has_ssse3()) { paeth_row_v<BPP>(x, prev, n); return true; }
+    return unfilter_row<BPP>(ft, x, prev, n);
 }
 
 // RGB -> BGR, 8 bits: five pixels per 16-byte load / store (the 16th byte is rewritten by the next store; the loop ends while 6 pixels remain)
@@ -202,21 +216,15 @@ __attribute__((target("ssse3"))) inline void rgb_to_bgr_row_ssse3(const unsigned
     for (; x < W; ++x, s += 3, q += 3) { const unsigned char r = s[0], g = s[1], b = s[2]; q[0] = b; q[1] = g; q[2] = r; }
 }
 
-bool cpu_has_ssse3() { static const bool v = __builtin_cpu_supports("ssse3"); return v; }
-
 bool unfilter_any(int bpp, int ft, unsigned char* x, const unsigned char* prev, size_t n)
 {
     switch (bpp) {
-    case 1: return unfilter_row<1>(ft, x, prev, n);
-    case 2: return unfilter_row<2>(ft, x, prev, n);
-    case 3:
-        if (ft == 1) { sub3_row(x, n); return true; }
-        if (prev && ft == 3) { avg3_row(x, prev, n); return true; }
-        if (prev && ft == 4 && n >= 9 && cpu_has_ssse3()) { paeth3_row_ssse3(x, prev, n); return true; }
-        return unfilter_row<3>(ft, x, prev, n);
-    case 4: return unfilter_row<4>(ft, x, prev, n);
-    case 6: return unfilter_row<6>(ft, x, prev, n);
-    case 8: return unfilter_row<8>(ft, x, prev, n);
+    case 1: return unfilter_px<1>(ft, x, prev, n);
+    case 2: return unfilter_px<2>(ft, x, prev, n);
+    case 3: return unfilter_px<3>(ft, x, prev, n);
+    case 4: return unfilter_px<4>(ft, x, prev, n);
+    case 6: return unfilter_px<6>(ft, x, prev, n);
+    case 8: return unfilter_px<8>(ft, x, prev, n);
     default: return false;
     }
 }

@@ -339,3 +339,26 @@ def test_many_small_idat_chunks_and_empty_ones():
     more = zlib.compress(zlib.decompress(z) + bytes(1 + 17 * 3))
     with pytest.raises(ValueError, match="more image data"):
         png.imread(b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", 17, 12, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", more) + _chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("ctype,depth", [(0, 8), (0, 16), (2, 8), (2, 16), (4, 8), (4, 16), (6, 8), (6, 16), (3, 8)])
+def test_row_kernels_every_pixel_size(ctype, depth):
+    """1, 2, 3, 4, 6 and 8 bytes per pixel through the vector row kernels (rows of 16 bytes and more) and the byte loops (shorter rows), every
+    filter type on every row position, smooth content (Paeth ties) and noise; the colour read's conversions as in test_other_colour_types"""
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    top = 200 if ctype == 3 else (1 << depth)
+    pal = RNG.integers(0, 256, (200, 3), dtype=np.uint8) if ctype == 3 else None
+    for W in (1, 5, 16, 33, 200):
+        H = 7
+        yy, xx = np.mgrid[0:H, 0:W]
+        smooth = np.stack([((3 + c) * xx + (5 - c) * yy * (257 if depth == 16 else 1)) % top for c in range(ch)], axis=2)
+        noise = RNG.integers(0, top, (H, W, ch))
+        for a in (smooth, noise):
+            a = a.astype(np.uint16 if depth == 16 else np.uint8)
+            for rot in range(5):
+                f = encode_png(a, ctype, depth, filters=tuple((rot + k) % 5 for k in range(5)), idat=1, palette=pal)
+                a8 = (a >> 8).astype(np.uint8) if depth == 16 else a
+                want = pal[a[:, :, 0]][:, :, ::-1] if ctype == 3 else (np.repeat(a8[:, :, :1], 3, axis=2) if ch <= 2 else a8[:, :, 2::-1])
+                assert np.array_equal(png.imread(f), want), (ctype, depth, W, rot)
+                if ctype == 0:
+                    assert np.array_equal(png.imread(f, unchanged=True), a[:, :, 0]), (depth, W, rot)

@@ -2,6 +2,10 @@
 # usage (GPU box, repo root): tools/final_profiles.sh <tag> — the subset of make_profiles.sh that must be taken on the FINAL sources: the bench line, its
 # kernel stats, the labelled layer sequences, and the two HBM-traffic JSONs whose build hash bench.py compares with the library's.
 tag=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
+# the counters first: bench.py reports them (roofline.traffic) only from files whose build hash is the library's
+tools/pmc_traffic.sh $tag 8 > /dev/null 2>&1
+tools/pmc_net.sh $tag 8 > /dev/null 2>&1
+cp $O/${tag}_resample_traffic.json $R/profiles/resample_traffic.json; cp $O/${tag}_network_traffic.json $R/profiles/network_traffic.json
 python bench.py > $O/${tag}_bench.log 2>&1; tail -1 $O/${tag}_bench.log > $O/${tag}_bench.json
 tools/prof_bench.sh $tag > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +17,6 @@ for b in 8 1; do
     python $R/tools/layerprof.py $(find $d -name "l_kernel_trace.csv" | head -1) v $d/labels.txt; } > $O/${tag}_layers_b$b.txt
 done
 cd $R
-tools/pmc_traffic.sh $tag 8 > /dev/null 2>&1
-tools/pmc_net.sh $tag 8 > /dev/null 2>&1
+# the raw traces (50 MB each) stay on the box: gpurun copies back at most 64 MiB
+rm -rf $O/prof_${tag} $O/prof_${tag}_b8 $O/prof_${tag}_b1
 ls -la $O | grep $tag

@@ -1247,55 +1247,78 @@ __global__ __launch_bounds__(256) void stem_f16x3_kernel(const float* __restrict
 }
 
 // ---- the stem with producer / consumer waves (option conv_stem_pc)
-// Eight waves: 0-3 consume (fragment reads, 72 matrix instructions per tile, stores), 4-7 produce (input pixels global -> registers -> hi / lo
+// Twelve waves: 0-7 consume (fragment reads, 36 matrix instructions per tile, stores), 8-11 produce (input pixels global -> registers -> hi / lo
 // split -> the NEXT tile's image in LDS, two image buffers) — loads and stores retire through one in-order counter, so a wave that does both
 // waits for its previous stores' acknowledges whenever it waits for pixels (as conv3x3_up2_g1_kernel found); one block barrier per tile.
-__global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
-                                                         const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po, int epi_lds)
+// Consumer wave w owns the two tile rows 2 (w & 3) and the 32 output channels of half w >> 2 (round 5; rounds 3-4: four consumers with both halves).
+// With ONE consumer per SIMD a tile cost its K loop (2.8 us: 144 LDS reads whose latency nothing hid) PLUS its epilogue (2.7 us) — 95 us for 144
+// patches with the matrix instructions themselves worth 12 (profiles/r05g_stem_ablations.txt); two consumers per SIMD run one's epilogue under the
+// other's K loop.  The A fragments are read twice (LDS traffic per tile 2.3 -> 3.1 k cycles); every output element is the same sum as before.
+__global__ __launch_bounds__(768) void stem_f16x3_pc_kernel(const float* __restrict__ src, const void* __restrict__ wt16,
+                                                         const float* __restrict__ bias, void* __restrict__ dst, int M, int P, int Po, int epi_lds, int tpb)
 {
     constexpr int IMG = 3 * SM_IH * SM_IP, IPT = (IMG + 255) / 256;
+    // rows are STORED 48 halfs apart (SM_IP = 40 are written and read): a wave's fragment read takes pixel rows y and y + 1 of two image rows each —
+    // 2 x 40 halfs = 40 dwords apart they share 8 of 32 banks (every read two passes), 48 dwords apart none
+    constexpr int SM_IS = 48, IMGS = 3 * SM_IH * SM_IS;
     __shared__ __attribute__((aligned(1024))) unsigned char wl[64 * SM_G * 128];
-    __shared__ __attribute__((aligned(16))) _Float16 imh[2][IMG], iml[2][IMG];                          // the input patch of a tile, split ONCE per pixel; two tiles
-    __shared__ __attribute__((aligned(16))) float etile[4][32 * 36];                                     // a transposition tile per consumer wave (epilogue_tile_lds, one 32-channel group at a time)
+    __shared__ __attribute__((aligned(16))) _Float16 imh[2][IMGS], iml[2][IMGS];                          // the input patch of a tile, split ONCE per pixel; two tiles
+    __shared__ __attribute__((aligned(16))) float etile[8][32 * 36];                                     // a transposition tile per consumer wave (epilogue_tile_lds: its 32-channel group)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int strips = Po / SM_TH;
-    const int m = blockIdx.x / strips, oy0 = (blockIdx.x % strips) * SM_TH;
-    // gridDim.y column ranges per strip (a lone panorama's 18 patches are 144 strips: a quarter strip per block fills the chip)
-    const int ox_first = blockIdx.y * (Po / gridDim.y), ox_last = ox_first + Po / gridDim.y;
+    // A block walks tpb consecutive tiles of the flat sequence (patch, strip of SM_TH rows, SM_TW columns): a quarter strip where the launch is small
+    // (a lone panorama's 18 patches are 576 tiles), 18 tiles = 4.5 strips at 8 panoramas — ONE block per CU for the whole launch: the filter bank is
+    // loaded once per CU instead of 4.5 times and the producers' pipeline is filled once (round 5; before: a strip per block, 4 tiles, 19 us per block
+    // of which 4 x ~2.5 were its tiles).
+    const int sps = Po / SM_TH, tps = Po / SM_TW, ntiles = M * sps * tps;
+    const int T0 = blockIdx.x * tpb, T1 = min(T0 + tpb, ntiles);
+    if (T0 >= T1) return;
+    auto where = [&](int T, int& m, int& oy0, int& ox0) { const int strip = T / tps; ox0 = (T - strip * tps) * SM_TW; m = strip / sps; oy0 = (strip - m * sps) * SM_TH; };
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // ---- producers
-        const int ft = t - 256;
+        const int ft = t - 512;
         float pre[IPT], nxt[IPT];
-        auto fetch = [&](int ox0, float (&v)[IPT]) {
-            const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+        // what does not depend on the tile, once per thread: the pixel's offset inside the patch's 3 x P x P image, its (row, column) inside the tile's
+        // input window, its LDS slot (the index arithmetic — divisions by 840 and 40, 64-bit address products — was ~30 quarter-rate integer
+        // multiplies per tile and wave: profiles/r05g_stem_ablations.txt)
+        int po[IPT], rq[IPT], ls[IPT];
 #pragma unroll
-            for (int k = 0; k < IPT; ++k) {                       // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
-                const int i = ft + 256 * k;
-                const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
-                const int iy = iy0 + r, ix = ix0 + q;
-                v[k] = (i < IMG && q < SM_IW && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) ? src[((size_t)m * 3 + c) * P * P + (size_t)iy * P + ix] : 0.0f;
+        for (int k = 0; k < IPT; ++k) {                           // (the pad columns 37..39 are read by the zero-weight kx = 7 lane slots)
+            const int i = ft + 256 * k;
+            const int c = i / (SM_IH * SM_IP), r = (i % (SM_IH * SM_IP)) / SM_IP, q = i % SM_IP;
+            po[k] = (c * P + r) * P + q;
+            rq[k] = (i < IMG && q < SM_IW) ? (r | (q << 8)) : -1;
+            ls[k] = i < IMG ? (i / SM_IP) * SM_IS + q : -1;
+        }
+        auto fetch = [&](int T, float (&v)[IPT]) {
+            int m, oy0, ox0;
+            where(T, m, oy0, ox0);
+            const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+            const float* base = src + (size_t)m * 3 * P * P + ((long long)iy0 * P + ix0);       // (wave-uniform; dereferenced only where the pixel exists)
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const int iy = iy0 + (rq[k] & 0xff), ix = ix0 + (rq[k] >> 8);
+                v[k] = (rq[k] >= 0 && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) ? base[po[k]] : 0.0f;
             }
         };
         auto park = [&](int b, const float (&v)[IPT]) {
 #pragma unroll
             for (int k = 0; k < IPT; ++k) {
-                const int i = ft + 256 * k;
                 const float x = v[k];
                 const _Float16 hh = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
-                if (i < IMG) { imh[b][i] = hh; iml[b][i] = (_Float16)((x - (float)hh) * 2048.0f); }
+                if (ls[k] >= 0) { imh[b][ls[k]] = hh; iml[b][ls[k]] = (_Float16)((x - (float)hh) * 2048.0f); }
             }
         };
-        fetch(ox_first, pre);
-        if (ox_first + SM_TW < ox_last) fetch(ox_first + SM_TW, nxt);
+        fetch(T0, pre);
+        if (T0 + 1 < T1) fetch(T0 + 1, nxt);
         park(0, pre);
         __syncthreads();                                          // (the consumers' first barrier)
         int b = 0;
-        for (int ox0 = ox_first + SM_TW; ox0 < ox_last; ox0 += SM_TW) {
+        for (int T = T0 + 1; T < T1; ++T) {
 #pragma unroll
             for (int k = 0; k < IPT; ++k) pre[k] = nxt[k];
-            if (ox0 + SM_TW < ox_last) fetch(ox0 + SM_TW, nxt);   // two tiles ahead: in flight while this one is split and parked
+            if (T + 1 < T1) fetch(T + 1, nxt);                    // two tiles ahead: in flight while this one is split and parked
             b ^= 1;
             park(b, pre);
             __syncthreads();
@@ -1304,15 +1327,14 @@ __global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restr
     }
 
     // ---- consumers.  filter bank -> LDS: SM_G regions of 64 rows x 128 B, same pair swizzle as the convolution tiles
+    const int pr = wave & 3, cj = wave >> 2;                      // tile rows 2 pr, 2 pr + 1; output channels 32 cj .. 32 cj + 31
     {
-        const int gs = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
-        const int rl = 8 * wave + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
+        const int gs = (lane & 15) ^ ((4 * pr + (lane >> 4)) & 15);
+        const int rl = 8 * pr + 2 * (lane >> 4) + (gs >> 3), pc16 = (gs & 7) * 16;
         const rsrc_t rsw = make_rsrc(wt16, (size_t)64 * SM_G * 128);
 #pragma unroll
         for (int g = 0; g < SM_G; ++g)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                dma16(rsw, wl + g * 8192 + wave * 1024 + i * 4096, ((rl + 32 * i) * SM_G + g) * 128 + pc16, 0);
+            dma16(rsw, wl + g * 8192 + pr * 1024 + cj * 4096, ((rl + 32 * cj) * SM_G + g) * 128 + pc16, 0);
     }
     int fo[4];
     {
@@ -1321,25 +1343,26 @@ __global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restr
         for (int k = 0; k < 4; ++k) fo[k] = v * 256 + ((((r & 1) * 8 + 2 * k + h) ^ v) * 16);
     }
     // this lane's output pixel inside a tile and its 12 fragment rows: fragment (g, kc) is input row (c, ky) = divmod(4g+2kc+h, 7)
-    const int py = 2 * wave + ((lane & 31) >> 4), px = lane & 15;
+    const int py = 2 * pr + ((lane & 31) >> 4), px = lane & 15;
     int rowoff[2 * SM_G];
 #pragma unroll
     for (int f = 0; f < 2 * SM_G; ++f) {
         int rr = 2 * f + (lane >> 5);
         rr = rr < 21 ? rr : 20;                                   // rows 21..23 carry zero weights: any finite data will do
-        rowoff[f] = ((rr / 7) * SM_IH + rr % 7 + 2 * py) * SM_IP + 2 * px;
+        rowoff[f] = ((rr / 7) * SM_IH + rr % 7 + 2 * py) * SM_IS + 2 * px;
     }
     ShConvArgs e;
     e.bias = bias; e.res = nullptr; e.res_f32 = 0; e.act = OMNI_ACT_RELU; e.Cout = 64; e.dst = dst; e.post = nullptr; e.post_rows = 1; e.epi_lds = epi_lds;
     wait_vm<0>();                                                 // the filter bank has landed
     __syncthreads();                                              // ... everybody's; the first image is there
-    int b = 0;
-    for (int ox0 = ox_first; ox0 < ox_last; ox0 += SM_TW) {
+    // the K loop of one tile (image buffer b) and the epilogue of one tile, as two steps: the channel halves run them in OPPOSITE order between two
+    // barriers — half 0: K loop(T), epilogue(T); half 1: epilogue(T - 1), K loop(T) — so that of the two consumers of a SIMD one is in its
+    // fragment reads / matrix instructions while the other is in its conversions / stores (in the same order both sat in the same phase: the
+    // tile cost the SUM of the two chains whatever the number of waves)
+    auto kloop = [&](int b, f16v (&acc)[1], f16v (&acc1)[1]) {
         const _Float16* ih = imh[b];
         const _Float16* il = iml[b];
-        f16v acc[2], acc1[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
+        acc[0] = (f16v)(0.0f); acc1[0] = (f16v)(0.0f);
 #pragma unroll
         for (int g = 0; g < SM_G; ++g)
 #pragma unroll
@@ -1353,32 +1376,45 @@ __global__ __launch_bounds__(512) void stem_f16x3_pc_kernel(const float* __restr
                     const h2v xh = *reinterpret_cast<const h2v*>(ih + ro + 2 * u), xl = *reinterpret_cast<const h2v*>(il + ro + 2 * u);
                     ah[2 * u] = xh[0]; ah[2 * u + 1] = xh[1]; al[2 * u] = xl[0]; al[2 * u + 1] = xl[1];
                 }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const unsigned char* bp = wl + g * 8192 + j * 4096;
-                    const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
-                    const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[j], 0, 0, 0);
-                }
+                const unsigned char* bp = wl + g * 8192 + cj * 4096;
+                const h8v bh = *reinterpret_cast<const h8v*>(bp + fo[kc]);
+                const h8v bl = *reinterpret_cast<const h8v*>(bp + fo[2 + kc]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc1[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc1[0], 0, 0, 0);
             }
-        const size_t r = ((size_t)m * Po + oy0 + py) * Po + ox0 + px;
-        const int c0[2] = {0, 32};
+    };
+    auto epi = [&](int T, const f16v (&acc)[1], const f16v (&acc1)[1]) {
+        int m, oy0, ox0;
+        where(T, m, oy0, ox0);
+        const int c0[1] = {32 * cj};
         if (e.epi_lds) {                                          // 151 MB of output at 8 panoramas: as 16-byte pieces (the wave's two rows of 16 pixels)
-            const size_t ra = ((size_t)m * Po + oy0 + 2 * wave) * Po + ox0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f16v ea[1] = {acc[j]}, eb[1] = {acc1[j]};
-                const int cj[1] = {32 * j};
-                epilogue_tile_lds<1>(ea, eb, e, ra, 32, cj, lane, etile[wave], ra + Po);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        } else epilogue_row<2>(acc, acc1, e, r, c0, lane, true);
-        if (ox0 + SM_TW >= ox_last) break;                        // (the producers leave at the same point: no barrier after the last tile)
-        wait_lds_reads();
-        __syncthreads();                                          // this image buffer is free, the other one is complete
-        b ^= 1;
+            const size_t ra = ((size_t)m * Po + oy0 + 2 * pr) * Po + ox0;
+            epilogue_tile_lds<1>(acc, acc1, e, ra, 32, c0, lane, etile[wave], ra + Po);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else epilogue_row<1>(acc, acc1, e, ((size_t)m * Po + oy0 + py) * Po + ox0 + px, c0, lane, true);
+    };
+    f16v acc[1], acc1[1];
+    int b = 0;
+    if (cj == 0) {
+        for (int T = T0; T < T1; ++T) {
+            kloop(b, acc, acc1);
+            epi(T, acc, acc1);
+            if (T + 1 >= T1) break;                               // (the producers leave at the same point: no barrier after the last tile)
+            wait_lds_reads();
+            __syncthreads();                                      // this image buffer is free, the other one is complete
+            b ^= 1;
+        }
+    } else {
+        for (int T = T0; T < T1; ++T) {
+            if (T > T0) epi(T - 1, acc, acc1);
+            kloop(b, acc, acc1);
+            if (T + 1 >= T1) break;
+            wait_lds_reads();
+            __syncthreads();
+            b ^= 1;
+        }
+        epi(T1 - 1, acc, acc1);
     }
 }
 
@@ -1976,7 +2012,14 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
     const int Po = P / 2;
     const int strips = M * (Po / SM_TH);
     const int split = (strips < 256 && Po % (4 * SM_TW) == 0) ? 4 : (strips < 512 && Po % (2 * SM_TW) == 0) ? 2 : 1;    // same bits either way
-    if (omni_options().conv_stem_pc) hipLaunchKernelGGL(stem_f16x3_pc_kernel, dim3(strips, split), dim3(512), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
+    if (omni_options().conv_stem_pc) {
+        // tiles per block: the column range of the split above where the launch is small; one block per CU walking ntiles / CUs tiles where it is not
+        const int tps = Po / SM_TW, ntiles = strips * tps;
+        int tpb = tps / split;
+        const int ncu = omni_num_cus();
+        if (split == 1 && ntiles > ncu * tps) tpb = (ntiles + ncu - 1) / ncu;
+        hipLaunchKernelGGL(stem_f16x3_pc_kernel, dim3((unsigned)((ntiles + tpb - 1) / tpb)), dim3(768), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds, tpb);
+    }
     else hipLaunchKernelGGL(stem_f16x3_kernel, dim3(strips, split), dim3(256), 0, (hipStream_t)stream, src, wt16, bias, dst, M, P, Po, omni_options().conv_epi_lds);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;

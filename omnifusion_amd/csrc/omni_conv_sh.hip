@@ -965,6 +965,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                 const unsigned char* bp = lds + W_OFF + (tap / 3) * B_BYTES + ((tap % 3) * BN) * 128;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    if (OMNI_ABL(512)) { fa[bf][k] = (h8v)((_Float16)(float)(a0 & 3)); fb[bf][k] = (h8v)((_Float16)(float)(fo[k] & 3)); continue; }   // (ablation: no fragment reads)
                     fa[bf][k] = *reinterpret_cast<const h8v*>(ha + (a0 ^ (k * 32)));
                     fb[bf][k] = *reinterpret_cast<const h8v*>(bp + fo[k]);
                 }
@@ -995,7 +996,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
             }
             __builtin_amdgcn_sched_barrier(0);
             if (OMNI_ABL(8192)) { acc += accy; acc1 += accx; }
-            if constexpr (HEADS) {
+            if constexpr (HEADS) if (OMNI_ABL(16384)) { if (acc[0] == 12345.678f && acc1[3] == 3.0f) hd.hr[lane] = acc[1]; } else {
                 // the tile's result stays in registers: v[q] = channels 8q + 4h .. + 3 of pixel lane & 31 — the lane's k chunk kc is its quads 2kc, 2kc + 1
                 h8v ph[2], pl[2];
 #pragma unroll

@@ -1,0 +1,56 @@
+// Issue rate of packed fp32 arithmetic on gfx950 (plain forms, inline assembly): does v_pk_mul_f32 / v_pk_fma_f32 cost one VALU slot (two results per
+// lane and slot) or two?  16 independent chains per thread, 4096 trips; 1 / 2 / 4 waves per SIMD.  Stand-alone: hipcc --offload-arch=gfx950 -O3 tools/pk_rate.hip -o /tmp/pk_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int MODE> __global__ __launch_bounds__(256) void rate_kernel(float* out, float s, int trips)
+{
+    f2v a[8]; float b[16];
+    for (int i = 0; i < 8; ++i) { a[i] = f2v{(float)threadIdx.x + i, 1.0f + i}; }
+    for (int i = 0; i < 16; ++i) b[i] = (float)threadIdx.x + i;
+    const f2v s2 = {s, s};
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (MODE == 0) {                                      // 16 scalar multiplies
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(b[i]) : "v"(s));
+            } else if (MODE == 1) {                               // 8 packed multiplies = the same 16 products
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(a[i]) : "v"(s2));
+            } else if (MODE == 2) {                               // 16 scalar fma
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(b[i]) : "v"(s));
+            } else {                                              // 8 packed fma
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %0, %0" : "+v"(a[i]) : "v"(s2));
+            }
+        }
+    }
+    float acc = 0.0f;
+    for (int i = 0; i < 8; ++i) acc += a[i].x + a[i].y;
+    for (int i = 0; i < 16; ++i) acc += b[i];
+    if (acc == 12345.678f) out[threadIdx.x] = acc;
+}
+template <int MODE> static void run(const char* name, float* out, int blocks)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int trips = 4096;
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1.0000001f, trips);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1.0000001f, trips);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double products = (double)blocks * 256 * trips * 4 * 16;
+    printf("%-22s blocks %5d (%d wave(s) per SIMD): %8.1f us  %7.2f G results/s  = %.2f results per lane-slot at 2.4 GHz x 256 CU x 64 lanes\n", name, blocks, blocks / 256, ms * 1e3,
+           products / ms * 1e-6, products / (ms * 1e-3) / (2.4e9 * 256 * 64));
+}
+int main()
+{
+    float* out; hipMalloc(&out, 1 << 20);
+    for (int blocks : {256, 512, 1024}) {
+        run<0>("v_mul_f32 x16", out, blocks); run<1>("v_pk_mul_f32 x8", out, blocks);
+        run<2>("v_fma_f32 x16", out, blocks); run<3>("v_pk_fma_f32 x8", out, blocks);
+    }
+    return 0;
+}

@@ -34,12 +34,15 @@
 
 // Compile-time ablations for tools/convabl.sh (a library variant per value; the product is built with 0): 4 no epilogue | 16, 32, 64 drop the
 // weight-lo / activation-lo / hi.hi product | 128 no operand DMA | 256 no block barrier in the K loop | 512 no fragment reads | conv3x3_up2_g1_kernel: 1024 no
-// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators.  (The debug
+// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators, 16384 no heads part, 32768 time stamps of block 0 (tools/g1_stamps.py).  (The debug
 // build's RUN-time bits put branches around the matrix instructions and run 2-5x slower than the product: useless for timing.)
 #ifndef OMNI_CONV_ABL
 #define OMNI_CONV_ABL 0
 #endif
 #define OMNI_ABL(bit) ((OMNI_CONV_ABL & (bit)) != 0)
+#ifndef OMNI_G1_PW
+#define OMNI_G1_PW 4                                           // producer waves of conv3x3_up2_g1_kernel<HEADS> (8: measured equal)
+#endif
 
 namespace {
 
@@ -902,12 +905,17 @@ constexpr int HR_PITCH = 36;                                 // floats per (tile
 struct HeadsArgs { const void* w16; float* hr; };           // w16: the heads' weights in fragment order (Engine: heads.w16f), [hi kc0, hi kc1, lo kc0, lo kc1][64 lanes] x 16 B
 
 template <bool HEADS>
-__global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int ntiles, HeadsArgs hd)
+__global__ __launch_bounds__(HEADS ? 64 * (4 + OMNI_G1_PW) : 512) void conv3x3_up2_g1_kernel(ShConvArgs a, int ntiles, HeadsArgs hd)
 {
     constexpr int BN = 32, TH = 4, NW = 4, RPP = 8 * NW;
+    constexpr int PW = HEADS ? OMNI_G1_PW : 4, CPT = 32 / PW;    // producer waves, channels per producer thread
     constexpr int HPX = (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
     constexpr int BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128, W_OFF = 2 * HA_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HA_BYTES + 3 * B_BYTES];
+    // (ablation 32768, tools/g1_stamps.py: s_memtime of consumer wave 0 / producer wave 4 of block 0 at three points of each of its first 40 tiles, written over hd.hr at the end)
+    constexpr int ST_N = 40, ST_K = 5;
+    __shared__ long long stamps[OMNI_ABL(32768) ? 2 * ST_N * ST_K : 1];
+    auto stamp = [&](int who, int it, int k) { if (OMNI_ABL(32768) && blockIdx.x == 0 && it < ST_N && (threadIdx.x & 63) == 0) stamps[(who * ST_N + it) * ST_K + k] = clock64(); };
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -918,7 +926,12 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
     const int per = (ntiles + 7) >> 3, t_end = min(ntiles, (xcd + 1) * per);
     int tile = xcd * per + lb;
     if (tile >= t_end) return;
-    auto origin = [&](int tl, int& m, int& y0, int& x0) { m = tl / per_img; const int r = tl - m * per_img; y0 = (r / tw) * TH; x0 = (r % tw) * HT_W; };
+    // tile -> (patch, tile row, tile column): divided ONCE per wave, then stepped — a producer spent 2400 of its 6400 cycles per tile in front of its loads, most of them
+    // in the three integer divisions per tile index (two indices per tile: profiles/r05h_up2_producer.txt, 8.)
+    struct TileXY { int m, ty, tx; };
+    auto coords = [&](int tl) { TileXY c; c.m = tl / per_img; const int r = tl - c.m * per_img; c.ty = r / tw; c.tx = r - c.ty * tw; return c; };
+    const TileXY tstep = coords(nlb);
+    auto advance = [&](TileXY& c) { c.tx += tstep.tx; c.ty += tstep.ty; c.m += tstep.m; if (c.tx >= tw) { c.tx -= tw; ++c.ty; } if (c.ty >= th) { c.ty -= th; ++c.m; } };
 
     if (consumer) {
         // ---- the nine taps' weights, once (three kernel-row stages of the halo kernel's layout, side by side)
@@ -955,8 +968,10 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
         }
         wait_vm<0>();                                             // weights (and bias) have landed
         __syncthreads();                                          // ... everybody's; the first halo is there
-        for (int it = 0;; ++it) {
+        TileXY ct = coords(tile);                                  // (the epilogue's tile)
+        for (int it = 0;; ++it, advance(ct)) {
             const unsigned char* ha = lds + (it & 1) * HA_BYTES;
+            if (wave == 0) stamp(0, it, 0);
             // the eight fragments of tap k+1 are read while the six matrix instructions of tap k run
             f16v acc = (f16v)(0.0f), acc1 = (f16v)(0.0f), accx = (f16v)(0.0f), accy = (f16v)(0.0f);
             h8v fa[2][4], fb[2][4];                               // [buffer][hi k0, hi k1, lo k0, lo k1] of the pixels / of the weights
@@ -996,6 +1011,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
             }
             __builtin_amdgcn_sched_barrier(0);
             if (OMNI_ABL(8192)) { acc += accy; acc1 += accx; }
+            if (wave == 0) stamp(0, it, 1);
             if constexpr (HEADS) if (OMNI_ABL(16384)) { if (acc[0] == 12345.678f && acc1[3] == 3.0f) hd.hr[lane] = acc[1]; } else {
                 // the tile's result stays in registers: v[q] = channels 8q + 4h .. + 3 of pixel lane & 31 — the lane's k chunk kc is its quads 2kc, 2kc + 1
                 h8v ph[2], pl[2];
@@ -1010,6 +1026,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ph[q >> 1][4 * (q & 1) + e] = hi[e]; pl[q >> 1][4 * (q & 1) + e] = lo[e]; }
                 }
+                if (OMNI_ABL(32768)) { if (ph[0][0] == (_Float16)77.0f && pl[1][3] == (_Float16)3.0f) hd.hr[1] = 1.0f; if (wave == 0) stamp(0, it, 2); }
                 f16v d0 = (f16v)(0.0f), d1 = (f16v)(0.0f);
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
@@ -1018,6 +1035,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                     d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwf[kc], pl[kc], d1, 0, 0, 0);
                 }
                 // rows (reg & 3) + 8 (reg >> 2) + 4 h: register group g = 0..2 is (dy, head) pair g + 3h, its registers 0..2 are dx = -1, 0, +1
+                if (OMNI_ABL(32768)) { if (d0[0] == 12345.678f && d1[5] == 3.0f) hd.hr[2] = 1.0f; if (wave == 0) stamp(0, it, 3); }
                 const int px = lane & 31, h = lane >> 5;
                 float* hp = hd.hr + ((size_t)tile * TH + wave) * (6 * HR_PITCH);
 #pragma unroll
@@ -1035,7 +1053,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
             } else
             {   // epilogue of this tile: column lane & 31 = pixel x0 + (lane & 31) of image row y0 + wave (through an LDS transposition, split-half or
                 // fp32: 247 | 248 us — the stores are not this kernel's limit, and 18 KB of LDS more per block are felt beside other kernels)
-                int m, y0, x0; origin(tile, m, y0, x0);
+                const int m = ct.m, y0 = ct.ty * TH, x0 = ct.tx * HT_W;
                 const size_t r = (size_t)(m * a.H + y0 + wave) * a.W + x0 + (lane & 31);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1054,79 +1072,102 @@ __global__ __launch_bounds__(512) void conv3x3_up2_g1_kernel(ShConvArgs a, int n
                     else               act_store4<false>(a.dst, o, v);
                 }
             }
+            if (wave == 0) stamp(0, it, 4);
             tile += nlb;
             if (tile >= t_end) break;
             wait_lds_reads();
             __syncthreads();                                      // this halo buffer is free, the other one is complete
         }
+        if (OMNI_ABL(32768) && blockIdx.x == 0 && wave == 0 && lane == 0) for (int i = 0; i < ST_N * ST_K; ++i) reinterpret_cast<long long*>(hd.hr)[i] = stamps[i];
         return;
     }
 
-    // ---- producers: thread (cell, 8 channels) of the 3 x 17 cells of 2 x 2 pixels of a tile's halo (see conv3x3_halo_sh_kernel, UP2)
+    // ---- producers: thread (cell, CPT channels) of the 3 x 17 cells of 2 x 2 pixels of a tile's halo (see conv3x3_halo_sh_kernel, UP2); PW = 4 producer waves: 8 channels
+    // per thread (the product); PW = 8: 4 channels per thread, two producer waves per SIMD (-DOMNI_G1_PW=8: measured equal, profiles/r05h_up2_producer.txt)
+    using hcv = std::conditional_t<CPT == 8, h8v, h4v>;
     const int ft = t - 64 * NW;
     const int Hl = a.H >> 1, Wl = a.W >> 1;
-    const int u_c8 = ft & 3, u_cell = ft >> 2, u_ci = u_cell / 17, u_cj = u_cell - u_ci * 17;
-    const bool filler = ft < 51 * 4;
-    auto load_src = [&](int tl, h8v (&ch)[4], h8v (&cl)[4]) {
+    constexpr int TPC = 32 / CPT;                                 // threads per cell
+    const int u_cg = ft % TPC, u_cell = ft / TPC, u_ci = u_cell / 17, u_cj = u_cell - u_ci * 17;
+    const int u_c8 = u_cg * CPT / 8, u_sub = (u_cg * CPT % 8) * 2; // 16-byte piece (8 channels) and byte offset inside it
+    const bool filler = ft < 51 * TPC;
+    auto load_src = [&](const TileXY& c, hcv (&ch)[4], hcv (&cl)[4]) {
         if (!filler) return;
-        int m, y0, x0; origin(tl, m, y0, x0);
+        const int m = c.m, y0 = c.ty * TH, x0 = c.tx * HT_W;
         const int u_k = (y0 >> 1) - 1 + u_ci, u_j = (x0 >> 1) - 1 + u_cj;
         const int ra = min(max(u_k, 0), Hl - 1), rb = min(max(u_k + 1, 0), Hl - 1), ca = min(max(u_j, 0), Wl - 1), cb = min(max(u_j + 1, 0), Wl - 1);
         const size_t img = (size_t)m * Hl * Wl;
-        const unsigned char* sp = (const unsigned char*)a.src1 + u_c8 * 16;
+        const unsigned char* sp = (const unsigned char*)a.src1 + u_cg * (CPT * 2);
         const size_t so[4] = {(img + (size_t)ra * Wl + ca) * 128, (img + (size_t)ra * Wl + cb) * 128, (img + (size_t)rb * Wl + ca) * 128, (img + (size_t)rb * Wl + cb) * 128};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (OMNI_ABL(4096)) { ch[q] = (h8v)((_Float16)1.0f); cl[q] = ch[q]; }
-            else { ch[q] = *reinterpret_cast<const h8v*>(sp + so[q]); cl[q] = *reinterpret_cast<const h8v*>(sp + so[q] + 64); }
+            if (OMNI_ABL(4096)) { ch[q] = (hcv)((_Float16)1.0f); cl[q] = ch[q]; }
+            else { ch[q] = *reinterpret_cast<const hcv*>(sp + so[q]); cl[q] = *reinterpret_cast<const hcv*>(sp + so[q] + 64); }
         }
     };
-    auto write_halo = [&](int tl, unsigned char* hb, const h8v (&ch)[4], const h8v (&cl)[4]) {
+    auto write_halo = [&](const TileXY& c, unsigned char* hb, const hcv (&ch)[4], const hcv (&cl)[4], int it) {
         if (!filler || OMNI_ABL(1024)) return;
-        int m, y0, x0; origin(tl, m, y0, x0);
+        const int y0 = c.ty * TH, x0 = c.tx * HT_W;
         const int u_k = (y0 >> 1) - 1 + u_ci, u_j = (x0 >> 1) - 1 + u_cj;
-        float v[4][8];
+        float v[4][CPT];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[q][e] = fmaf((float)cl[q][e], 4.8828125e-4f, (float)ch[q][e]);
+            for (int e = 0; e < CPT; ++e) v[q][e] = fmaf((float)cl[q][e], 4.8828125e-4f, (float)ch[q][e]);
+        if (OMNI_ABL(32768)) { float z = 0.0f; for (int q = 0; q < 4; ++q) for (int e = 0; e < CPT; ++e) z += v[q][e]; if (z == 12345.678f) hd.hr[0] = z; if (wave == NW) stamp(1, it, 1); }
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+        for (int dy = 0; dy < 2; ++dy) {
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int oy = 2 * u_k + 1 + dy, ox = 2 * u_j + 1 + dx;
                 const float fy = fmaxf(0.5f * ((float)oy + 0.5f) - 0.5f, 0.0f), fx = fmaxf(0.5f * ((float)ox + 0.5f) - 0.5f, 0.0f);
                 const float ly = fy - (float)(int)fy, lx = fx - (float)(int)fx, hy = 1.0f - ly, hx = 1.0f - lx;
                 const bool in = (unsigned)oy < (unsigned)a.H && (unsigned)ox < (unsigned)a.W;
-                h8v oh, ol;
+                hcv oh, ol;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int e = 0; e < CPT; ++e) {
                     const float o = hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]);
                     const _Float16 hh = (fabsf(o) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)o;
                     oh[e] = in ? hh : (_Float16)0.0f;
                     ol[e] = in ? (_Float16)((o - (float)hh) * 2048.0f) : (_Float16)0.0f;
                 }
                 const int p = (2 * u_ci + dy) * HPW + 2 * u_cj + dx, d = p >> 1, pc = (p & 1) * 8 + u_c8;
-                *reinterpret_cast<h8v*>(hb + d * 256 + ((pc ^ (d & 15)) * 16)) = oh;
-                *reinterpret_cast<h8v*>(hb + d * 256 + (((pc + 4) ^ (d & 15)) * 16)) = ol;
+                *reinterpret_cast<hcv*>(hb + d * 256 + ((pc ^ (d & 15)) * 16) + u_sub) = oh;
+                *reinterpret_cast<hcv*>(hb + d * 256 + (((pc + 4) ^ (d & 15)) * 16) + u_sub) = ol;
             }
+            if (dy == 0 && wave == NW) stamp(1, it, 2);
+        }
     };
     // the pixels of tile k+2 are on their way while the halo of tile k+1 is computed (a producer issues no stores: its waits are for loads only)
-    h8v ch[4], cl[4], nh[4], nl[4];
-    load_src(tile, ch, cl);
-    if (tile + nlb < t_end) load_src(tile + nlb, nh, nl);
-    write_halo(tile, lds, ch, cl);
+    // Two register sets in turn, no copies: a set is re-loaded (tile k+2) as soon as its halo (tile k) is written — the loads are issued at the END of a tile's work,
+    // the arithmetic starts right behind the barrier.
+    hcv rh[2][4], rl_[2][4];
+    TileXY cw = coords(tile), cn = cw;                            // the tile whose halo is written next / the tile loaded last
+    load_src(cw, rh[0], rl_[0]);
+    advance(cn);
+    if (tile + nlb < t_end) load_src(cn, rh[1], rl_[1]);
+    write_halo(cw, lds, rh[0], rl_[0], ST_N);
+    cw = cn; advance(cn);
+    if (tile + 2 * nlb < t_end) load_src(cn, rh[0], rl_[0]);
     __syncthreads();                                              // (the consumers' first barrier)
-    for (int it = 0;; ++it) {
-        const int next = tile + nlb;
-        if (next >= t_end) break;                                 // (the consumers leave at the same point: no barrier after the last tile)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ch[q] = nh[q]; cl[q] = nl[q]; }
-        if (next + nlb < t_end) load_src(next + nlb, nh, nl);
-        write_halo(next, lds + ((it + 1) & 1) * HA_BYTES, ch, cl);
-        __syncthreads();
-        tile = next;
+    int it = 0;
+#define OMNI_G1_STEP(SET) { \
+        const int next = tile + nlb; \
+        if (wave == NW) stamp(1, it, 0); \
+        if (next >= t_end) break;                                 /* (the consumers leave at the same point: no barrier after the last tile) */ \
+        write_halo(cw, lds + ((it + 1) & 1) * HA_BYTES, rh[SET], rl_[SET], it); \
+        if (wave == NW) stamp(1, it, 3); \
+        cw = cn; advance(cn); \
+        if (next + 2 * nlb < t_end) load_src(cn, rh[SET], rl_[SET]); \
+        if (wave == NW) stamp(1, it, 4); \
+        __syncthreads(); \
+        tile = next; ++it; }
+    for (;;) {
+        OMNI_G1_STEP(1)
+        OMNI_G1_STEP(0)
     }
+#undef OMNI_G1_STEP
+    if (OMNI_ABL(32768) && blockIdx.x == 0 && wave == NW && lane == 0) for (int i = 0; i < ST_N * ST_K; ++i) reinterpret_cast<long long*>(hd.hr)[ST_N * ST_K + i] = stamps[ST_N * ST_K + i];
 }
 
 // ------------------------------------------------------------------ stem: conv 7x7 s2 p3, 3 -> 64, + folded BN + ReLU (f16x3)
@@ -1928,7 +1969,7 @@ extern "C" int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16
     a.M = M; a.H = P; a.W = P; a.C1 = 32; a.C2 = 0; a.Cout = 32; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = OMNI_ACT_RELU;
     a.Ho = P; a.Wo = P; a.rows = M * P * P; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1; a.sk_tickets = nullptr; a.sk_tp = 0;
     const int grid = M * (P / 4) * (P / HT_W);
-    hipLaunchKernelGGL(conv3x3_up2_g1_kernel<true>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid, HeadsArgs{heads_w16f, scratch});
+    hipLaunchKernelGGL(conv3x3_up2_g1_kernel<true>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(64 * (4 + OMNI_G1_PW)), 0, (hipStream_t)stream, a, grid, HeadsArgs{heads_w16f, scratch});
     OMNI_HIP(hipGetLastError());
     const size_t n = (size_t)M * P * P / 4;
     hipLaunchKernelGGL(heads_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, bias_pred, bias_weight,

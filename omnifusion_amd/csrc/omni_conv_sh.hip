@@ -1333,9 +1333,12 @@ __global__ __launch_bounds__(768) void stem_f16x3_pc_kernel(const float* __restr
             rq[k] = (i < IMG && q < SM_IW) ? (r | (q << 8)) : -1;
             ls[k] = i < IMG ? (i / SM_IP) * SM_IS + q : -1;
         }
-        auto fetch = [&](int T, float (&v)[IPT]) {
-            int m, oy0, ox0;
-            where(T, m, oy0, ox0);
+        // the tile whose pixels are fetched next: (patch, strip, column tile), divided once and stepped
+        int fm, fs, fc;
+        { const int strip = T0 / tps; fc = T0 - strip * tps; fm = strip / sps; fs = strip - fm * sps; }
+        auto fetch = [&](float (&v)[IPT]) {                       // ... and steps to the following tile
+            const int m = fm, oy0 = fs * SM_TH, ox0 = fc * SM_TW;
+            if (++fc == tps) { fc = 0; if (++fs == sps) { fs = 0; ++fm; } }
             const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
             const float* base = src + (size_t)m * 3 * P * P + ((long long)iy0 * P + ix0);       // (wave-uniform; dereferenced only where the pixel exists)
 #pragma unroll
@@ -1352,18 +1355,25 @@ __global__ __launch_bounds__(768) void stem_f16x3_pc_kernel(const float* __restr
                 if (ls[k] >= 0) { imh[b][ls[k]] = hh; iml[b][ls[k]] = (_Float16)((x - (float)hh) * 2048.0f); }
             }
         };
-        fetch(T0, pre);
-        if (T0 + 1 < T1) fetch(T0 + 1, nxt);
+        // Two register sets in turn: a set is re-fetched (tile T + 2) as soon as it is parked — the loads are issued at the END of a tile's work, when the consumers are
+        // in their epilogues, not behind the barrier where their fragment reads start (conv3x3_up2_g1_kernel's producers stood a whole K loop in front of their loads there:
+        // profiles/r05h_up2_producer.txt, 8.-9.)
+        fetch(pre);
+        if (T0 + 1 < T1) fetch(nxt);
         park(0, pre);
+        if (T0 + 2 < T1) fetch(pre);
         __syncthreads();                                          // (the consumers' first barrier)
-        int b = 0;
-        for (int T = T0 + 1; T < T1; ++T) {
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) pre[k] = nxt[k];
-            if (T + 1 < T1) fetch(T + 1, nxt);                    // two tiles ahead: in flight while this one is split and parked
-            b ^= 1;
-            park(b, pre);
+        int b = 0, T = T0 + 1;
+        for (;;) {
+            if (T >= T1) break;
+            b ^= 1; park(b, nxt);
+            if (T + 2 < T1) fetch(nxt);
             __syncthreads();
+            if (++T >= T1) break;
+            b ^= 1; park(b, pre);
+            if (T + 2 < T1) fetch(pre);
+            __syncthreads();
+            ++T;
         }
         return;
     }

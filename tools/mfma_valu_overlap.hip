@@ -28,8 +28,10 @@ template <int OP> __global__ __launch_bounds__(512) void overlap_kernel(float* o
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    if (OP) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(b[i]) : "v"(s));
-                    else    asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(b[i]) : "v"(s));
+                    if (OP == 1)      asm volatile("v_mul_f32 %0, %1, %0" : "+v"(b[i]) : "v"(s));
+                    else if (OP == 2) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(b[i]) : "v"(s));          // (quarter-rate integer multiply: address arithmetic)
+                    else if (OP == 3) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(b[i]));
+                    else              asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(b[i]) : "v"(s));
                 }
         }
         float x = 0.0f; for (int i = 0; i < 16; ++i) x += b[i];
@@ -48,7 +50,7 @@ template <int OP> static float run(float* out, int mode, int mt, int vt)
 template <int OP> static void sweep(float* out, const char* name)
 {
     const int mt = 2000;                       // 16 000 matrix instructions per matrix wave
-    for (int vt : {2000, 1000, 500, 250}) {    // 128 000 ... 16 000 vector instructions per vector wave
+    for (int vt : {2000 / (OP == 2 ? 4 : 1), 1000 / (OP == 2 ? 4 : 1), 500 / (OP == 2 ? 4 : 1), 250 / (OP == 2 ? 4 : 1)}) {    // 128 000 ... 16 000 vector instructions per vector wave (a quarter of that for the quarter-rate multiply)
         const float tm = run<OP>(out, 1, mt, vt), tv = run<OP>(out, 2, mt, vt), tb = run<OP>(out, 3, mt, vt);
         printf("%s x %6d per vector wave: matrix waves alone %7.1f us (%.1f ns per instruction and SIMD) | vector waves alone %7.1f us (%.2f ns per instruction) | both %7.1f us = %.2f x max, %.2f x sum\n",
                name, vt * 64, tm, tm * 1e3 / (mt * 8), tv, tv * 1e3 / (vt * 64), tb, tb / (tm > tv ? tm : tv), tb / (tm + tv));
@@ -57,6 +59,6 @@ template <int OP> static void sweep(float* out, const char* name)
 int main()
 {
     float* out; hipMalloc(&out, 1 << 20);
-    sweep<0>(out, "v_fma_f32"); sweep<1>(out, "v_mul_f32");
+    sweep<0>(out, "v_fma_f32"); sweep<1>(out, "v_mul_f32"); sweep<2>(out, "v_mul_lo_u32"); sweep<3>(out, "v_cvt_f16_f32");
     return 0;
 }

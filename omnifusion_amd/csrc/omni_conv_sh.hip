@@ -34,7 +34,7 @@
 
 // Compile-time ablations for tools/convabl.sh (a library variant per value; the product is built with 0): 4 no epilogue | 16, 32, 64 drop the
 // weight-lo / activation-lo / hi.hi product | 128 no operand DMA | 256 no block barrier in the K loop | 512 no fragment reads | conv3x3_up2_g1_kernel: 1024 no
-// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators, 16384 no heads part, 32768 time stamps of block 0 (tools/g1_stamps.py).  (The debug
+// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators, 16384 no heads part, 32768 time stamps of block 0 (tools/g1_stamps.py; conv3x3_halo_sh_kernel: tools/halo_stamps.py).  (The debug
 // build's RUN-time bits put branches around the matrix instructions and run 2-5x slower than the product: useless for timing.)
 #ifndef OMNI_CONV_ABL
 #define OMNI_CONV_ABL 0
@@ -681,6 +681,13 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
     constexpr int HPX = IW > 0 ? NSUB * HPS : (TH + 2) * HPW, HA_INSTR = (HPX * 8 + 63) / 64, HA_BYTES = HA_INSTR * 1024;
     constexpr int APASS = (HA_INSTR + NW - 1) / NW, BROWS = 3 * BN, BPASS = (BROWS + RPP - 1) / RPP, B_BYTES = BROWS * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[HA_BYTES + 2 * B_BYTES];
+    // (ablation 32768, tools/halo_stamps.py: s_memtime of wave 0 of blocks 0 and 600 — start, prologue done, per K stage: before its waits / behind the barrier / weights
+    //  issued / matrix instructions issued, epilogue done — dumped to a.ws)
+    __shared__ long long hst[OMNI_ABL(32768) ? 64 : 1];
+    const bool stamped = OMNI_ABL(32768) && (blockIdx.x == 0 || blockIdx.x == 600) && a.ws != nullptr;
+    auto hstamp = [&](int k) { if (OMNI_ABL(32768) && stamped && threadIdx.x == 0 && k < 64) hst[k] = clock64(); };
+    auto hdump = [&]() { if (OMNI_ABL(32768) && stamped && threadIdx.x == 0) for (int i = 0; i < 64; ++i) reinterpret_cast<long long*>(a.ws)[(blockIdx.x ? 64 : 0) + i] = hst[i]; };
+    hstamp(0);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ntn = a.Cout / BN, tw = IW > 0 ? 1 : a.W / HT_W, th = IW > 0 ? 1 : a.H / TH;
@@ -824,18 +831,23 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
 #pragma unroll
     for (int j = 0; j < TN; ++j) { acc[j] = (f16v)(0.0f); acc1[j] = (f16v)(0.0f); }
 
+    hstamp(63);
     if constexpr (UP2) { issue_b(0, 0, 0); fill_a(0); }            // (the weights travel while the halo is computed)
     else               { issue_a(0); issue_b(0, 0, 0); }
     int buf = 0;
+    hstamp(1);
     for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
+            hstamp(4 + 4 * (3 * g + ky));
             wait_vm<0>();                                         // halo (ky == 0) and this kernel row's weights have landed
             wait_lds_reads();                                     // ... and my reads of the other weight buffer have returned
             if (!OMNI_ABL(256)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            hstamp(5 + 4 * (3 * g + ky));
             if (ky < 2) issue_b(g, ky + 1, buf ^ 1);              // next weights under this row's matrix work
             else if (g + 1 < G) issue_b(g + 1, 0, buf ^ 1);
+            hstamp(6 + 4 * (3 * g + ky));
             const unsigned char* sB = lds + HA_BYTES + buf * B_BYTES;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
@@ -856,6 +868,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
                 }
             }
             buf ^= 1;
+            hstamp(7 + 4 * (3 * g + ky));
         }
         if (g + 1 < G) {                                          // everybody is done with this group's halo: fetch the next
             wait_lds_reads();
@@ -874,10 +887,16 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
         static_assert(TH * 32 * (32 * TN + 4) * 4 <= (int)sizeof(lds), "the transposition tiles must fit the K loop's buffers");
         wait_lds_reads();
         __syncthreads();                                          // every wave is done with the halo and the weights
+        hstamp(2);
         epilogue_tile_lds<TN>(acc, acc1, a, (size_t)(r - (lane & 31)), 32, c0, lane, reinterpret_cast<float*>(lds) + wave * (32 * (32 * TN + 4)));
+        hstamp(62);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        hstamp(3); hdump();
         return;
     }
+    hstamp(2);
     epilogue_row<TN>(acc, acc1, a, (size_t)r, c0, lane, a.dst_sh != 0);
+    hstamp(3); hdump();
 }
 
 // ------------------------------------------------------------------ de_conv4_0: conv3x3(up2(x)), 32 -> 32 channels, PERSISTENT

@@ -34,7 +34,7 @@
 
 // Compile-time ablations for tools/convabl.sh (a library variant per value; the product is built with 0): 4 no epilogue | 16, 32, 64 drop the
 // weight-lo / activation-lo / hi.hi product | 128 no operand DMA | 256 no block barrier in the K loop | 512 no fragment reads | conv3x3_up2_g1_kernel: 1024 no
-// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators, 16384 no heads part, 32768 time stamps of block 0 (tools/g1_stamps.py; conv3x3_halo_sh_kernel: tools/halo_stamps.py).  (The debug
+// halo arithmetic, 2048 no stores, 4096 no pixel loads, 8192 four accumulators, 16384 no heads part, 32768 time stamps of block 0 (tools/g1_stamps.py; conv3x3_halo_sh_kernel: tools/halo_stamps.py; conv_sh_kernel: tools/tile_stamps.py).  (The debug
 // build's RUN-time bits put branches around the matrix instructions and run 2-5x slower than the product: useless for timing.)
 #ifndef OMNI_CONV_ABL
 #define OMNI_CONV_ABL 0
@@ -297,6 +297,12 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
     __shared__ unsigned sk_ticket;                                // SK: this unit's arrival number on its tile's counter
+    // (ablation 32768, tools/tile_stamps.py: s_memtime of matrix wave 0 and of the first loader wave of block 0 around the parts of its first 28 K steps, dumped to a.ws)
+    __shared__ long long cst[OMNI_ABL(32768) ? 256 : 1];
+    const bool stamped = OMNI_ABL(32768) && blockIdx.x == 0 && blockIdx.y == 0 && a.ws != nullptr && a.splitk <= 1;
+    auto cstamp = [&](int k) { if (OMNI_ABL(32768) && stamped && (threadIdx.x & 63) == 0 && k < 256) cst[k] = clock64(); };
+    auto cdump = [&]() { if (OMNI_ABL(32768) && stamped && threadIdx.x == 0) for (int i = 0; i < 256; ++i) reinterpret_cast<long long*>(a.ws)[i] = cst[i]; };
+    if (threadIdx.x == 0) cstamp(0);
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: LDS-DMA bases stay in scalar registers
@@ -437,11 +443,16 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
         // ks-1) -> the pieces of stage ks+NST-1 into the slot stage ks-1 occupied
         auto lstep = [&](int ks, auto slot_c) {
             constexpr int SLOT = decltype(slot_c)::value;
+            const int sk_ = 128 + 4 * (ks - ks_begin);
+            if (wave == NW && ks - ks_begin < 28) cstamp(sk_);
             if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
             else                       wait_vm<0>();
+            if (wave == NW && ks - ks_begin < 28) cstamp(sk_ + 1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (wave == NW && ks - ks_begin < 28) cstamp(sk_ + 2);
             if (ks + NST - 1 < ks_end) issue(ks + NST - 1, std::integral_constant<int, (SLOT + NST - 1) % NST>());
+            if (wave == NW && ks - ks_begin < 28) cstamp(sk_ + 3);
         };
         int ks = ks_begin;
         for (; ks + NST - 1 < ks_end; ks += NST) {
@@ -470,9 +481,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
             if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
             else                       wait_vm<0>();
         }
+        if (wave == 0 && ks - ks_begin < 28) cstamp(8 + 4 * (ks - ks_begin));
         wait_lds_reads();                                        // my fragment reads of stage ks-1 have returned ...
         if (!OMNI_ABL(256)) __builtin_amdgcn_s_barrier();     // ... everybody's pieces have landed; everybody is done reading stage ks-1
         asm volatile("" ::: "memory");
+        if (wave == 0 && ks - ks_begin < 28) cstamp(9 + 4 * (ks - ks_begin));
         const unsigned char* sl = lds + SLOT * STAGE;
         h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
         if (OMNI_ABL(512)) {                                  // (ablation: no fragment reads)
@@ -524,6 +537,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
         ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
     }(std::make_integer_sequence<int, NST - 1>());
 
+    if (wave == 0) cstamp(1);                                     // K loop issued
     if (OMNI_ABL(4) || OMNI_DBG(a, 4)) return;
     if constexpr (SK) {
         if (a.splitk > 1) {
@@ -608,6 +622,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
             if (r0 < a.rows) epilogue_tile_lds<TN, false>(acc[i], acc1[i], a, (size_t)r0, min(32, a.rows - r0), c0, lane, tile);
             if (i + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the tile is read back before it is written again)
         }
+        if (OMNI_ABL(32768)) { if (wave == 0) cstamp(2); __syncthreads(); cdump(); }
         return;
     }
 #pragma unroll

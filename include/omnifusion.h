@@ -200,22 +200,6 @@ int omni_gemm_rows_ln_sh_f16x3(const float* x, const float* ln_weight, const flo
  * 2Wl % 32 == 0 and 2Hl % 4 == 0 (else OMNI_ERR_UNSUPPORTED: omni_upsample_bilinear_sh + omni_conv2d_sh_f16x3_ws give the same bits). */
 int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, const float* bias, void* dst, int fmt,
                               int M, int Hl, int Wl, int C, int Cout, int act, omni_stream_t stream);
-/* Transformer_cascade (model/spherical_model.py:169-187, model/blocks.py:14-89) of a small batch in ONE cooperative launch: 6 x [LN1 + qkv | attention |
- * proj + residual | LN2 + fc1 + GELU | fc2 + residual] + encoder_norm, device-wide barriers between the phases, every block's next weights in flight
- * while it waits.  A layer record holds DEVICE pointers: LayerNorm weights / biases and the proj / fc1 / fc2 biases fp32; the four matrices in the fragment
- * order of omni_gemm_rows_pack — qkv = cat(attn.q.weight, attn.kv.weight) [1536,512], proj [512,512], fc1 [2048,512], fc2 [512,2048].  tok fp32 [B*N,512]
- * (token + pos_emb; overwritten), out fp32 [B*N,512] = encoder_norm of the result; scratch omni_transformer_scratch_bytes(B*N) bytes; sync: TWO zero-
- * initialised 32-bit counters per execution context (stream), left zero.  N <= 64, B*N <= 4096.  Element for element the arithmetic of
- * omni_gemm_rows_ln_sh_f16x3 / omni_attention_qkv_sh / omni_gemm_rows_sh_f16x3 / omni_layernorm512_f32 (same bits), for every panorama of the batch. */
-typedef struct {
-    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *proj_b, *fc1_b, *fc2_b;
-    const void *qkv_w16r, *proj_w16r, *fc1_w16r, *fc2_w16r;
-} omni_xf_layer;
-size_t omni_transformer_scratch_bytes(int M);
-int omni_transformer_sh_f16x3(float* tok, const omni_xf_layer* layers, const float* enc_w, const float* enc_b, float* out,
-                              void* scratch, size_t scratch_bytes, unsigned* sync, int B, int N, omni_stream_t stream);
-/* *timeouts = 1 if a block of omni_transformer_sh_f16x3 ever gave up waiting at a device-wide barrier (grid not co-resident for ~1 s).  Synchronises. */
-int omni_transformer_status(int* timeouts, int reset);
 /* de_conv4_0 AND the two heads in one pass over the widest tensor of the network (model/spherical_model.py:300-307: F.interpolate + ConvBnReLU 32 -> 32,
  * then pred (ReLU) / weight_pred (sigmoid), 3x3, 32 -> 1, and their product): a = relu(pred(y)) * (confidence ? sigmoid(weight_pred(y)) : 1),
  * c = sigmoid(weight_pred(y)); y = de_conv4_0's output never exists.  src SH [M,P/2,P/2,32]; heads_w16f from omni_heads_pack_f16x3; scratch of
@@ -233,23 +217,6 @@ int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void*
                                  const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                  int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                                  const float* post, size_t post_elems, omni_stream_t stream);
-/* omni_conv2d_sh_f16x3_ws whose split-K reduction happens INSIDE the launch (replaces the second pass the reference never
- * needed: one cuDNN call per Conv3d, model/spherical_model.py:259-261,270-302).  `tickets`: ntickets zero-initialised 32-bit counters owned by
- * the caller's execution context (launches sharing them must be stream-ordered; the kernel leaves them zero); ws: omni_conv2d_sk_ws_bytes()
- * bytes.  The launch is a 1-D grid of (tile, K segment) units; all segments of a tile run on ONE XCD, leave their partial tiles in its L2 and
- * the last to arrive sums them in segment order and runs the epilogue: the bits of the two-launch form with the same splitk.  Without
- * tickets (NULL), with a smaller workspace or with option conv_sk = 0 the two-launch form runs. */
-int omni_conv2d_sh_f16x3_sk_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
-                               const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
-                               int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                               unsigned* tickets, size_t ntickets, omni_stream_t stream);
-size_t omni_conv2d_sk_ws_bytes(long long rows, int Cout, int splitk);
-/* split factor for a caller WITH tickets: (tile, segment) units sized to fill the 256 CUs from one launch (rows = the NOMINAL row count, as for
- * omni_conv2d_splitk_plan: the factor must not depend on the batch).  KH .. pad: the launch's shape — 1 where the launch takes a halo kernel. */
-int omni_conv2d_sk_plan(long long rows, int Cout, int ksteps, int KH, int KW, int stride, int pad, int H, int W);
-/* *violations = 1 if a block of an in-launch reduction ever found itself on another XCD than its block id implies (the premise of the
- * hand-over through one XCD's L2; checked by every block against the hardware's XCC_ID).  Synchronises: diagnostic only. */
-int omni_conv_sk_status(int* violations, int reset);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a

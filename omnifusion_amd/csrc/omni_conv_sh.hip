@@ -108,7 +108,6 @@ struct ShConvArgs {
     int wt_major;                            // 1: an XCD's contiguous block range walks tile_m fastest — it owns a range of OUTPUT-CHANNEL tiles and touches only their weights (conv_sh_kernel)
     int epi_lds;                             // 1: SH epilogues through an LDS transposition (16-byte pieces), OMNI_CONV_EPI_LDS
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
-    unsigned* sk_tickets; int sk_tp;         // SK kernels (in-kernel reduction): one arrival counter per tile (zero between launches); tiles per XCD
     const float* post; unsigned post_rows;   // fp32 [post_rows][Cout] added AFTER the activation, row index modulo post_rows (layer1 + point_feat), or null
 };
 
@@ -264,30 +263,10 @@ __device__ __forceinline__ void splitk_finish(f4v v, size_t o, const float* __re
     }
 }
 
-// ------------------------------------------------------------------ split-K with the reduction INSIDE the launch (template flag SK)
-// The K segmentation is the plan's (splitk ranges of ceil(ksteps / splitk) steps, exactly the two-launch form's: same bits), but the
-// partial tiles never meet in a second kernel: a launch is a 1-D grid of (tile, segment) UNITS, every unit leaves its partial tile in the
-// workspace, takes a ticket on the tile's arrival counter, and the unit that arrives LAST sums the partial tiles IN SEGMENT ORDER (its
-// own from registers) and runs the ordinary epilogue.  Rounds 2-3 built this twice and dropped it: partial tiles that cross XCDs need
-// device-scope release / acquire (L2 write-back + invalidate), which cost more than the reduce launch.  Here they never cross: hardware
-// block b runs on XCD b % 8 (profiles/r03a_cu_map.txt), so all segments of a tile are given block ids of ONE residue class — unit
-// u = 8 i + x: XCD x, tile x * sk_tp + i / splitk, segment i % splitk — and meet in that XCD's L2, which is coherent for its 32 CUs: plain
-// stores (write-through L1), an L2 atomic without device scope, loads that bypass L1 (sc1).  No fence, no cache maintenance.
-// Every block checks the premise against the hardware's XCC_ID register and raises a sticky flag (omni_conv_sk_status) if it ever fails.
-// Partial tiles are stored in FRAGMENT order ([unit][wave][tile][quad][lane] x 16 B: a wave's store / load is one contiguous KiB).
-__device__ unsigned sk_violation_flag = 0;
-
-__device__ __forceinline__ f4v sk_load16(rsrc_t rs, unsigned voff)
-{
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const u4v r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 16);      // aux 16 = sc1: past the L1, from this XCD's L2
-    return __builtin_bit_cast(f4v, r);
-}
-
 // NL > 0: NL extra LOADER waves issue every LDS-DMA piece of the block and wait for them; the WM x WN matrix waves never touch vector memory
 // inside the K loop (a piece costs the issuing wave 100-185 cycles between matrix instructions: four pieces per K-step against twelve
 // matrix instructions of 32).  Same pieces, same LDS image, same K order: same bits.
-template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0, bool SK = false>           // NST stages in flight (the step loop is unrolled by it)
+template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>           // NST stages in flight (the step loop is unrolled by it)
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs a)
 {
     constexpr int NW = WM * WN, LW = NL > 0 ? NL : NW, RPP = 8 * LW;   // matrix waves; waves that issue DMA; tile rows covered by one DMA pass of the block
@@ -296,7 +275,6 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     static_assert(APASS >= 1 && BPASS >= 1, "a tile side must cover at least one DMA pass");
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
-    __shared__ unsigned sk_ticket;                                // SK: this unit's arrival number on its tile's counter
     // (ablation 32768, tools/tile_stamps.py: s_memtime of matrix wave 0 and of the first loader wave of block 0 around the parts of its first 28 K steps, dumped to a.ws)
     __shared__ long long cst[OMNI_ABL(32768) ? 256 : 1];
     const bool stamped = OMNI_ABL(32768) && blockIdx.x == 0 && blockIdx.y == 0 && a.ws != nullptr && a.splitk <= 1;
@@ -315,15 +293,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     // (wt_major — the WEIGHTS are the larger operand: layer4's 9.4 MB against 4.7 MB of pixels, the transformer's matrices against 144 token
     //  rows — an XCD gets a range of output-channel tiles instead and fetches 1/8 of the weights rather than all of them; same tiles, same bits)
     const int ntm = (a.rows + BM - 1) / BM;
-    unsigned lb, sk_seg = 0;
-    if constexpr (SK) {
-        const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-        const unsigned p = i / (unsigned)a.splitk;
-        sk_seg = i - p * (unsigned)a.splitk;
-        lb = x * (unsigned)a.sk_tp + p;                           // XCD x owns the tiles x * sk_tp .. x * sk_tp + sk_tp - 1 (neighbours share operands in its L2)
-        if (p >= (unsigned)a.sk_tp || lb >= (unsigned)(ntm * ntn)) return;                  // a padding unit (the whole block)
-        if (t == 0 && ((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) != x) atomicOr(&sk_violation_flag, 1u);   // XCC_ID: the premise of the in-L2 hand-over
-    } else lb = a.noxcd ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned lb = a.noxcd ? blockIdx.x : omni_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = a.wt_major ? (int)(lb % (unsigned)ntm) : (int)(lb / (unsigned)ntn), tile_n = a.wt_major ? (int)(lb / (unsigned)ntm) : (int)(lb % (unsigned)ntn);
     const int row0 = tile_m * BM, col0 = tile_n * BN;
     const int G1 = a.C1 >> 5, G2 = a.C2 >> 5, G = G1 + G2;
@@ -430,7 +400,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     int ks_begin = 0, ks_end = ksteps;
     if (a.splitk > 1) {
         const int per = (ksteps + a.splitk - 1) / a.splitk;
-        ks_begin = (SK ? (int)sk_seg : (int)blockIdx.y) * per; ks_end = min(ksteps, ks_begin + per);
+        ks_begin = (int)blockIdx.y * per; ks_end = min(ksteps, ks_begin + per);
     }
     if (NL == 0 || loader) {
         seek(ks_begin);
@@ -462,14 +432,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
         [&]<int... S>(std::integer_sequence<int, S...>) {
             ((ks + S < ks_end ? lstep(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
         }(std::make_integer_sequence<int, NST - 1>());
-        if constexpr (SK) {
-            if (a.splitk > 1) {                                   // the matrix waves' hand-over barriers (partials stored; ticket published)
-                __syncthreads();
-                __syncthreads();
-                if (sk_ticket != (unsigned)a.splitk - 1u) return;
-            }
-        }
-        if ((SK || a.splitk <= 1) && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) __syncthreads();    // (the barrier in front of the LDS epilogue)
+        if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) __syncthreads();    // (the barrier in front of the LDS epilogue)
         return;
     }
 
@@ -539,76 +502,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
 
     if (wave == 0) cstamp(1);                                     // K loop issued
     if (OMNI_ABL(4) || OMNI_DBG(a, 4)) return;
-    if constexpr (SK) {
-        if (a.splitk > 1) {
-            // ---- hand-over through this XCD's L2 (see above): partial tile out, ticket, the last arrival sums in segment order
-            constexpr int UNIT16 = NW * TM * TN * 4 * 64;        // 16-byte pieces of one unit's partial tile
-            const rsrc_t rsp = make_rsrc(a.ws, (size_t)8 * a.sk_tp * a.splitk * UNIT16 * 16);
-            const unsigned ubase = lb * (unsigned)a.splitk * UNIT16, mine = (unsigned)((wave * TM * TN) * 4 * 64 + lane);
-            f4v* wsp = reinterpret_cast<f4v*>(a.ws);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(acc1[i][j][e], 4.8828125e-4f, acc[i][j][e]);     // the partial sum the two-launch form stores
-                    acc1[i][j] = (f16v)(0.0f);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f4v v; v.x = acc[i][j][4 * q]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
-                        wsp[ubase + sk_seg * UNIT16 + mine + ((i * TN + j) * 4 + q) * 64] = v;
-                    }
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces are in the L2 ...
-            wait_lds_reads();
-            __syncthreads();                                      // ... everybody's are
-            if (t == 0) {
-                sk_ticket = __hip_atomic_fetch_add(a.sk_tickets + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (an L2 atomic, no device scope)
-            }
-            __syncthreads();
-            if (sk_ticket != (unsigned)a.splitk - 1u) return;
-            if (t == 0) a.sk_tickets[lb] = 0;                    // the counter is clean for the next launch (nobody else touches it any more)
-            // sum_s partial[s], s ascending, opened by partial[0] (the reduce kernel's order: same bits); this unit's own tile comes from `acc`,
-            // the running sum is built in `acc1`
-            auto piece = [&](unsigned sg, int i, int j, int q) -> f4v {
-                return sk_load16(rsp, (ubase + sg * UNIT16 + mine + ((i * TN + j) * 4 + q) * 64) * 16u);
-            };
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (sk_seg == 0) acc1[i][j] = acc[i][j];
-                    else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f4v v = piece(0, i, j, q);
-                            acc1[i][j][4 * q] = v.x; acc1[i][j][4 * q + 1] = v.y; acc1[i][j][4 * q + 2] = v.z; acc1[i][j][4 * q + 3] = v.w;
-                        }
-                    }
-                }
-            for (unsigned sg = 1; sg < (unsigned)a.splitk; ++sg) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (sg == sk_seg) acc1[i][j] += acc[i][j];
-                        else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f4v v = piece(sg, i, j, q);
-                                acc1[i][j][4 * q] += v.x; acc1[i][j][4 * q + 1] += v.y; acc1[i][j][4 * q + 2] += v.z; acc1[i][j][4 * q + 3] += v.w;
-                            }
-                        }
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { acc[i][j] = acc1[i][j]; acc1[i][j] = (f16v)(0.0f); }     // (the epilogues form acc + 2^-11 acc1 = acc, exactly)
-        }
-    }
     // ---- epilogue.  D = W x pixels: column (lane & 31) = pixel, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel
-    if ((SK || a.splitk <= 1) && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {       // (`post`: only the halo kernel takes it through LDS — the registers it costs would spill here) split-half output: through LDS, 16-byte pieces (epilogue_tile_lds)
+    if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) {       // (`post`: only the halo kernel takes it through LDS — the registers it costs would spill here) split-half output: through LDS, 16-byte pieces (epilogue_tile_lds)
         static_assert(NW * 32 * (32 * TN + 4) * 4 <= NST * STAGE, "the transposition tiles must fit the K loop's buffers");
         wait_lds_reads();
         __syncthreads();                                          // every wave is done with the last stage
@@ -629,7 +524,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     for (int i = 0; i < TM; ++i) {
         const int r = row0 + wm * (BM / WM) + i * 32 + (lane & 31);
         if (r >= a.rows) continue;
-        if (!SK && a.splitk > 1) {
+        if (a.splitk > 1) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1734,29 +1629,12 @@ __global__ __launch_bounds__(512) void gemm_rows_ln_sh_kernel(RowsGemmArgs a, co
 }
 
 template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>
-void launch_sh(ShConvArgs a, hipStream_t s, bool sk)
+void launch_sh(ShConvArgs a, hipStream_t s)
 {
     const int tiles = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
-    if (sk && a.splitk > 1) {                                      // the reduction inside the launch: 1-D grid of (tile, segment) units, XCD-major (see conv_sh_kernel)
-        a.sk_tp = (tiles + 7) / 8;
-        hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, NL, true>), dim3(8 * a.sk_tp * a.splitk), dim3(64 * (WM * WN + NL)), 0, s, a);
-        return;
-    }
     hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, NL>), dim3(tiles, a.splitk > 1 ? a.splitk : 1), dim3(64 * (WM * WN + NL)), 0, s, a);
 }
 
-// workspace bytes the in-launch reduction needs for the LARGEST footprint any tile choice can have: (tiles rounded up to 8) x splitk x tile bytes
-size_t sk_ws_bytes(long long rows, int Cout, int splitk)
-{
-    size_t best = 0;
-    const int cfg[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
-    for (auto& c : cfg) {
-        if (Cout % c[1]) continue;
-        const size_t tiles = (size_t)((rows + c[0] - 1) / c[0]) * (size_t)(Cout / c[1]);
-        best = std::max(best, (tiles + 7) / 8 * 8 * (size_t)splitk * c[0] * c[1] * sizeof(float));
-    }
-    return best;
-}
 }  // namespace
 
 // out[M,Ho,Wo,Cout] = act(conv(src1 ++ src2, wt16) + bias + res) with SH activations (see the file header).
@@ -1766,21 +1644,17 @@ size_t sk_ws_bytes(long long rows, int Cout, int splitk)
 // Requirements: C1, C2, Cout multiples of 32, kernels up to 3x3.  split-K as in omni_conv2d_nhwc_f32_ws.
 // `post` (or null): fp32 [post_elems / Cout][Cout] added after the activation, output row index modulo its row count — layer1 + point_feat
 // (model/spherical_model.py:258) inside layer1's last convolution instead of a pass of its own.  Not with split-K.
-// `tickets` (or null): ntickets zero-initialised 32-bit counters owned by the caller's execution context (one buffer per stream: launches that share
-// it must be stream-ordered) — with them a split-K launch reduces INSIDE the kernel (conv_sh_kernel<.., SK>: no second launch, partial tiles stay in
-// one XCD's L2, summed in segment order: the bits of the two-launch form).  ws must then hold omni_conv2d_sk_ws_bytes(rows, Cout, splitk) bytes;
-// a smaller workspace, null tickets or option conv_sk = 0 select the two-launch form.
 static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, const float* bias,
                           const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                           int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                          const float* post, size_t post_elems, unsigned* tickets, size_t ntickets, omni_stream_t stream);
+                          const float* post, size_t post_elems, omni_stream_t stream);
 extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
                                        const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                        int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                                        omni_stream_t stream)
 {
     return conv2d_sh_impl(src1, src2, wt16, bias, res, dst, fmt, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes,
-                          nullptr, 0, nullptr, 0, stream);
+                          nullptr, 0, stream);
 }
 extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
                                             const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
@@ -1788,69 +1662,14 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
                                             const float* post, size_t post_elems, omni_stream_t stream)
 {
     return conv2d_sh_impl(src1, src2, wt16, bias, res, dst, fmt, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes,
-                          post, post_elems, nullptr, 0, stream);
-}
-extern "C" int omni_conv2d_sh_f16x3_sk_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
-                                          const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
-                                          int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                                          unsigned* tickets, size_t ntickets, omni_stream_t stream)
-{
-    return conv2d_sh_impl(src1, src2, wt16, bias, res, dst, fmt, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes,
-                          nullptr, 0, tickets, ntickets, stream);
-}
-extern "C" size_t omni_conv2d_sk_ws_bytes(long long rows, int Cout, int splitk)
-{
-    if (rows <= 0 || Cout <= 0 || splitk <= 1) return 0;
-    return std::max(sk_ws_bytes(rows, Cout, splitk), (size_t)splitk * (size_t)rows * Cout * sizeof(float));    // (also enough for the two-launch form)
+                          post, post_elems, stream);
 }
 extern "C" int omni_conv2d_splitk_plan(long long rows, int Cout, int ksteps);            // omni_conv.hip: the two-launch plan
 
-// Split factor for a caller with tickets.  Cost model in K-steps of a 128-row tile: a launch is ceil(units / 256) rounds of one unit per CU,
-// a unit costs its K segment + FIX (prologue, pipeline fill, partial tile out), the last arrival REDUCE more; a split must buy >= 10 %.
-// (rows = the nominal row count: the factor — and with it every output bit — must not depend on the batch.)
-extern "C" int omni_conv2d_sk_plan(long long rows, int Cout, int ksteps, int KH, int KW, int stride, int pad, int H, int W)
-{
-    const int two = omni_conv2d_splitk_plan(rows, Cout, ksteps);
-    const int mode = omni_options().conv_sk_plan;
-    if (mode == 0 || !omni_options().conv_sk || rows <= 0 || Cout <= 0 || ksteps < 8) return two;
-    // launches that take a halo kernel when unsplit stay unsplit (conv2d_sh_impl's conditions)
-    const bool s1 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && !omni_options().conv_nohalo;
-    const bool halo_img = s1 && H == W && (W == 16 || (W == 8 && omni_options().conv_img >= 2)) && Cout % 64 == 0 && omni_options().conv_img > 0;
-    const bool halo_wide = s1 && W % 32 == 0 && H % 4 == 0;
-    if (two <= 1 && (halo_img || halo_wide)) return 1;
-    const int smax = std::min(32, ksteps / 4);
-    if (mode > 1) return std::max(1, std::min(mode, smax));
-    const int bn = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
-    const long long tiles = ((rows + 127) / 128) * (Cout / bn);
-    const double FIX = 8.0, REDUCE = 3.0;
-    auto cost = [&](int s) {
-        const long long rounds = (tiles * s + 255) / 256;
-        return rounds * ((ksteps + s - 1) / s + FIX) + (s > 1 ? REDUCE + 0.25 * s : 0.0);
-    };
-    int best = 1;
-    double cb = cost(1) * 0.9;                                     // a split must buy >= 10 %
-    for (int s = 2; s <= smax; ++s)
-        if (cost(s) < cb) { cb = cost(s); best = s; }
-    if (const int cap = omni_options().splitk_max; cap > 0 && best > cap) best = cap;
-    return best;
-}
-
-// sticky flag of the in-launch reduction's premise (hardware block b runs on XCD b % 8): *violations = 1 if any block ever found itself on another XCD
-// (results of that launch may be wrong); synchronises — a diagnostic entry point like omni_sh_overflow
-extern "C" int omni_conv_sk_status(int* violations, int reset)
-{
-    if (!violations) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv_sk_status: null output");
-    OMNI_HIP(hipDeviceSynchronize());
-    unsigned v = 0;
-    OMNI_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(sk_violation_flag), sizeof(v)));
-    if (reset && v) { const unsigned z = 0; OMNI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sk_violation_flag), &z, sizeof(z))); }
-    *violations = v ? 1 : 0;
-    return OMNI_OK;
-}
 static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, const float* bias,
                           const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                           int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                          const float* post, size_t post_elems, unsigned* tickets, size_t ntickets, omni_stream_t stream)
+                          const float* post, size_t post_elems, omni_stream_t stream)
 {
     const int dst_sh = fmt & 1;
     if (!src1 || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: null pointer");
@@ -1879,10 +1698,6 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     if (S > 1 && (!ws || ws_bytes < (size_t)S * rows * Cout * sizeof(float)))
         OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: split-K workspace too small");
     a.splitk = S > 1 ? S : 1; a.ws = ws;
-    a.sk_tickets = tickets; a.sk_tp = 0;
-    // the reduction inside the launch (conv_sh_kernel<.., SK>) when the caller brought tickets and a workspace for any tile choice; same bits either way
-    const bool sk = S > 1 && tickets && omni_options().conv_sk && ws_bytes >= sk_ws_bytes(rows, Cout, S) && ws_bytes < (1ull << 32) &&
-                    ntickets >= (size_t)(((rows + 63) / 64) * (Cout / 32) + 8);
     // block order of conv_sh_kernel: weight-stationary per XCD where the weight matrix is larger than the activation tensor(s) (option conv_wt_major:
     // 1 auto | 0 never | 2 always)
     a.wt_major = omni_options().conv_wt_major == 2 || (omni_options().conv_wt_major == 1 &&
@@ -1928,27 +1743,27 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     // 0: 64x64 everywhere; 1: 128x64 (4 waves); 2: 128x128 (4 waves); 3 / 4: the 8-wave forms everywhere; 5..7: auto without 256x128, with 64 / 128 / 256 blocks
     int tile = omni_options().conv_sh_tile;
     if (tile < 0) tile = 8;
-    if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s, sk);
-    else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s, sk);
-    else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s, sk);
-    else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s, sk);            // 8 waves
-    else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s, sk);
-    else if (tile == 8 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s, sk);   // each wave a 64x64 tile: 0.67 KB of LDS reads per MFMA instead of 1
+    if (Cout % 64 != 0) launch_sh<128, 32, 4, 1>(a, s);
+    else if (tile == 2 && Cout % 128 == 0) launch_sh<128, 128, 2, 2>(a, s);
+    else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
+    else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s);            // 8 waves
+    else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
+    else if (tile == 8 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s);   // each wave a 64x64 tile: 0.67 KB of LDS reads per MFMA instead of 1
     // (128x128 and 128x64 with four LOADER waves beside the eight matrix waves: layer3 51.3 -> 45.8 us, de_conv0_0 90 -> 79, layer4 43.3 -> 41.3, same bits;
     //  tile = 9: without them.  256x128 has no registers to spare for a third wave per SIMD.)
-    else if (tile == 8 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2, 3, 4>(a, s, sk);
-    else if (tile == 8 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2, 3, 4>(a, s, sk);
-    else if (tile == 9 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s, sk);
-    else if (tile == 9 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2>(a, s, sk);
-    else if (tile == 9 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2>(a, s, sk);
-    else if (tile >= 5 && tile <= 7 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 128, 4, 2>(a, s, sk);
-    else if (tile >= 5 && tile <= 7 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 64, 4, 2>(a, s, sk);
+    else if (tile == 8 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2, 3, 4>(a, s);
+    else if (tile == 8 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2, 3, 4>(a, s);
+    else if (tile == 9 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s);
+    else if (tile == 9 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2>(a, s);
+    else if (tile == 9 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= 128) launch_sh<128, 64, 4, 2>(a, s);
+    else if (tile >= 5 && tile <= 7 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 128, 4, 2>(a, s);
+    else if (tile >= 5 && tile <= 7 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 64, 4, 2>(a, s);
     // one round of at most one block per CU (the transformer GEMMs; every deep layer at batch 1): the K loop is pure latency,
     // keep 5 stages in flight instead of 2 (96 KiB of LDS, which a single resident block can afford)
-    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !omni_options().conv_nodeep) launch_sh<64, 64, 2, 2, 6>(a, s, sk);
-    else launch_sh<64, 64, 2, 2>(a, s, sk);
+    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !omni_options().conv_nodeep) launch_sh<64, 64, 2, 2, 6>(a, s);
+    else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
-    if (a.splitk > 1 && !sk) {
+    if (a.splitk > 1) {
         const size_t n4 = (size_t)rows * Cout / 4;
         hipLaunchKernelGGL(sh_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, bias, res, dst,
                            n4, Cout, a.splitk, (size_t)rows * Cout, act, a.dst_sh, a.res_f32);
@@ -2011,7 +1826,7 @@ extern "C" int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16
     a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = nullptr; a.dst_sh = 0; a.res_f32 = 0;
     a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.wt_major = 0; a.epi_lds = 0;
     a.M = M; a.H = P; a.W = P; a.C1 = 32; a.C2 = 0; a.Cout = 32; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = OMNI_ACT_RELU;
-    a.Ho = P; a.Wo = P; a.rows = M * P * P; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1; a.sk_tickets = nullptr; a.sk_tp = 0;
+    a.Ho = P; a.Wo = P; a.rows = M * P * P; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
     const int grid = M * (P / 4) * (P / HT_W);
     hipLaunchKernelGGL(conv3x3_up2_g1_kernel<true>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(64 * (4 + OMNI_G1_PW)), 0, (hipStream_t)stream, a, grid, HeadsArgs{heads_w16f, scratch});
     OMNI_HIP(hipGetLastError());
@@ -2114,14 +1929,13 @@ extern "C" int omni_stem_sh_f16x3(const float* src, const void* wt16, const floa
 // layout conversions (n = number of elements, a multiple of 32 channels per pixel)
 OMNI_SH_OVERFLOW_ACCESSOR(omni_sh_overflow_conv)          // this translation unit's copy of the sticky range flag
 int omni_sh_overflow_net(unsigned* out, int reset);      // omni_net.hip's
-int omni_sh_overflow_xformer(unsigned* out, int reset);  // omni_xformer.hip's
 
 extern "C" int omni_sh_overflow(int* flag, int reset)
 {
     if (!flag) OMNI_FAIL(OMNI_ERR_INVALID, "omni_sh_overflow: null output");
     OMNI_HIP(hipDeviceSynchronize());                    // diagnostic entry point, never on the hot path
     unsigned v = 0;
-    if (omni_sh_overflow_conv(&v, reset) != 0 || omni_sh_overflow_net(&v, reset) != 0 || omni_sh_overflow_xformer(&v, reset) != 0)
+    if (omni_sh_overflow_conv(&v, reset) != 0 || omni_sh_overflow_net(&v, reset) != 0)
         OMNI_FAIL(OMNI_ERR_HIP, "omni_sh_overflow: could not read the device flag");
     *flag = v ? 1 : 0;
     return OMNI_OK;

@@ -34,8 +34,6 @@ const OptName kOpts[] = {
     {"conv_epi_lds", "OMNI_CONV_EPI_LDS", &OmniOptions::conv_epi_lds, 1},
     {"conv_up2_persist", "OMNI_CONV_UP2_PERSIST", &OmniOptions::conv_up2_persist, 1},
     {"splitk_max", "OMNI_SPLITK_MAX", &OmniOptions::splitk_max, 0},
-    {"conv_sk", "OMNI_CONV_SK", &OmniOptions::conv_sk, 0},
-    {"conv_sk_plan", "OMNI_CONV_SK_PLAN", &OmniOptions::conv_sk_plan, 1},
     {"e2p_gather", "OMNI_E2P_GATHER", &OmniOptions::e2p_gather, 0},
     {"e2p_notab", "OMNI_E2P_NOTAB", &OmniOptions::e2p_notab, 0},
     {"e2p_verbose", "OMNI_E2P_VERBOSE", &OmniOptions::e2p_verbose, 0},

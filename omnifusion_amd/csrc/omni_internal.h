@@ -36,8 +36,6 @@ struct OmniOptions {
     int conv_epi_lds;     // OMNI_CONV_EPI_LDS   1 (default): split-half outputs of the convolution kernels leave through an LDS transposition, 16 bytes per lane | 0: 8 bytes per lane straight from the accumulators
     int conv_up2_persist; // OMNI_CONV_UP2_PERSIST 1 (default): conv3x3(up2(x)) with 32 -> 32 channels (de_conv4_0) on the persistent kernel with resident weights | 0: the halo kernel
     int splitk_max;       // OMNI_SPLITK_MAX     cap of the split-K plan (0 = none)
-    int conv_sk;          // OMNI_CONV_SK        0 (default): split-K = two launches | 1: a split-K launch whose caller brings tickets reduces INSIDE the kernel (ordered, in one XCD's L2: the bits of the two-launch form).  EXPERIMENTAL: measured slower (profiles/r05a_sk_conv.txt), and its premise — block b on XCD b % 8 — holds for ONE stream only: with kernels of several streams in flight blocks land elsewhere (omni_conv_sk_status reports it)
-    int conv_sk_plan;     // OMNI_CONV_SK_PLAN   split-K plan for callers with tickets (omni_conv2d_sk_plan): 1 (default) fill 256 CUs with (tile, segment) units | 0: the two-launch plan | n > 1: that factor wherever the tile kernel runs (experiments)
     int e2p_gather;       // OMNI_E2P_GATHER     1: equi2pers always takes the direct-gather kernel (no LDS staging)
     int e2p_notab;        // OMNI_E2P_NOTAB      1: no per-geometry sampling-coordinate table
     int e2p_verbose;      // OMNI_E2P_VERBOSE    1: print tile statistics when a geometry handle is built

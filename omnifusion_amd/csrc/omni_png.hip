@@ -13,6 +13,7 @@
 // Supported: colour types 0 (gray), 2 (RGB), 3 (palette), 4 (gray + alpha), 6 (RGB + alpha) at 8 bits, types 0 / 2 / 4 / 6 at 16 bits; no
 // interlacing (Adam7) and no 1/2/4-bit samples (OMNI_ERR_UNSUPPORTED; neither occurs in the dataset).
 #include <string.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
@@ -229,6 +230,10 @@ bool unfilter_any(int bpp, int ft, unsigned char* x, const unsigned char* prev, 
     }
 }
 
+// the free list of scratch buffers (png_decode_body's Lease) and its lock: at namespace scope so that the fork handlers below can hold the lock across fork()
+std::mutex& lease_mu() { static std::mutex m; return m; }
+std::vector<std::pair<std::vector<unsigned char>, std::vector<unsigned char>>>& lease_pool() { static std::vector<std::pair<std::vector<unsigned char>, std::vector<unsigned char>>> p; return p; }
+
 // kind 0: cv2.imread(path) -> uint8 BGR [H,W,3];  kind 1: cv2.imread(path, -1) of a single-channel file -> uint8 / uint16 [H,W] in host byte order
 int png_decode_body(const unsigned char* d, size_t n, void* dst, int H, int W, int kind, int* elem_bytes)
 {
@@ -239,10 +244,8 @@ int png_decode_body(const unsigned char* d, size_t n, void* dst, int H, int W, i
     // per thread on 8 threads, 80 MB/s on 64)
     struct Lease {
         std::vector<unsigned char> buf, zbuf;
-        Lease() { std::lock_guard<std::mutex> lk(mu()); if (!pool().empty()) { buf.swap(pool().back().first); zbuf.swap(pool().back().second); pool().pop_back(); } }
-        ~Lease() { std::lock_guard<std::mutex> lk(mu()); if (pool().size() < 256 && buf.capacity() <= (64u << 20) && zbuf.capacity() <= (64u << 20)) pool().emplace_back(std::move(buf), std::move(zbuf)); }
-        static std::mutex& mu() { static std::mutex m; return m; }
-        static std::vector<std::pair<std::vector<unsigned char>, std::vector<unsigned char>>>& pool() { static std::vector<std::pair<std::vector<unsigned char>, std::vector<unsigned char>>> p; return p; }
+        Lease() { std::lock_guard<std::mutex> lk(lease_mu()); if (!lease_pool().empty()) { buf.swap(lease_pool().back().first); zbuf.swap(lease_pool().back().second); lease_pool().pop_back(); } }
+        ~Lease() { std::lock_guard<std::mutex> lk(lease_mu()); if (lease_pool().size() < 256 && buf.capacity() <= (64u << 20) && zbuf.capacity() <= (64u << 20)) lease_pool().emplace_back(std::move(buf), std::move(zbuf)); }
     } lease;
     std::vector<unsigned char>& raw = lease.buf;
     unsigned char pal[256][3];
@@ -343,13 +346,30 @@ extern "C" int omni_png_checksums(const void* data, size_t nbytes, unsigned* crc
 // A process-wide pool of decoder threads, started on first use: a batch call used to create (and join) its own std::threads — with several batch
 // decoders side by side that was ~18 000 thread creations per second, each an 8-MB stack mmap / munmap under the process's address-space lock, and the
 // whole loader levelled off at 2300 panoramas/s whatever the number of decoders (round 5, tools/png_fed_ab.py).
+//
+// fork(): torch DataLoader workers (the reference's test.py:90-97) are forked children; a child inherits the pool OBJECT but none of its threads, and
+// any mutex another thread held at the moment of the fork stays locked for ever.  pthread_atfork handlers (registered with the pool's first use) hold
+// the three locks of this file across the fork — so the child finds them unlocked and the structures consistent — and the child ABANDONS the inherited
+// pool (never destroyed: its std::thread members are joinable and their threads do not exist); the child's first batch call starts a pool of its own.
 namespace {
 class PngPool {
 public:
-    static PngPool& get() { static PngPool p; return p; }
+    static PngPool& get()
+    {
+        std::lock_guard<std::mutex> lk(create_mu());
+        static const int registered = pthread_atfork(&PngPool::fork_prepare, &PngPool::fork_parent, &PngPool::fork_child);
+        (void)registered;
+        if (!instance()) instance() = new PngPool();               // (never deleted: the threads sleep on the queue until the process ends)
+        return *instance();
+    }
     void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); } cv_.notify_one(); }
     int size() const { return (int)th_.size(); }
 private:
+    static std::mutex& create_mu() { static std::mutex m; return m; }
+    static PngPool*& instance() { static PngPool* p = nullptr; return p; }
+    static void fork_prepare() { create_mu().lock(); lease_mu().lock(); if (instance()) instance()->mu_.lock(); }
+    static void fork_parent() { if (instance()) instance()->mu_.unlock(); lease_mu().unlock(); create_mu().unlock(); }
+    static void fork_child() { if (instance()) instance()->mu_.unlock(); instance() = nullptr; lease_mu().unlock(); create_mu().unlock(); }
     PngPool()
     {
         int n = (int)std::thread::hardware_concurrency();
@@ -366,26 +386,19 @@ private:
         if (quota > 0 && period > 0) n = std::max(2, std::min(n, (int)((quota + period - 1) / period)));
         for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
     }
-    ~PngPool()
-    {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
     void run()
     {
         for (;;) {
             std::function<void()> f;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
-                if (stop_ && q_.empty()) return;
+                cv_.wait(lk, [this] { return !q_.empty(); });
                 f = std::move(q_.front()); q_.pop_front();
             }
             f();
         }
     }
-    std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> th_; bool stop_ = false;
+    std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> th_;
 };
 }  // namespace
 
@@ -397,10 +410,11 @@ extern "C" int omni_png_decode_batch(const void* const* datas, const size_t* nby
     if (kind != 0 && kind != 1) OMNI_FAIL(OMNI_ERR_INVALID, "omni_png_decode_batch: kind must be 0 or 1");
     if (n == 0) return OMNI_OK;
     struct Call {
-        std::atomic<int> next{0}, left{0}, status{OMNI_OK};
+        std::atomic<int> next{0}, status{OMNI_OK};
+        int running = 0; bool closed = false;                       // (under mu) helpers inside work(); the caller has run out of images: later helpers return at once
         std::string first_error; std::mutex mu; std::condition_variable done;
     };
-    // (shared with the helpers: the last helper may still be inside its unlock / notify when the caller wakes up and returns)
+    // (shared with the helpers: a helper that the pool schedules after the caller has returned finds `closed` and touches nothing else)
     const std::shared_ptr<Call> callp = std::make_shared<Call>();
     Call& call = *callp;
     auto work = [&, callp]() {                                      // takes images until none is left (a pool thread, or the caller)
@@ -420,17 +434,22 @@ extern "C" int omni_png_decode_batch(const void* const* datas, const size_t* nby
         if (threads > 1) helpers = std::min(helpers, threads);
         helpers -= 1;                                               // the calling thread decodes too
     }
-    call.left.store(helpers);
     for (int t = 0; t < helpers; ++t)
         PngPool::get().submit([callp, &work] {
-            work();                                                 // (`work` and what it references live on the caller's stack: the caller does not return before left == 0)
+            {
+                std::lock_guard<std::mutex> lk(callp->mu);
+                if (callp->closed) return;                          // every image is taken (the caller may have returned: `work` is gone) — a busy pool costs the caller no wait
+                ++callp->running;
+            }
+            work();                                                 // (`work` and what it references live on the caller's stack: the caller does not return while running > 0)
             std::lock_guard<std::mutex> lk(callp->mu);
-            if (callp->left.fetch_sub(1) == 1) callp->done.notify_all();
+            if (--callp->running == 0) callp->done.notify_all();
         });
     work();
     if (helpers > 0) {
         std::unique_lock<std::mutex> lk(call.mu);
-        call.done.wait(lk, [&] { return call.left.load() == 0; });
+        call.closed = true;                                         // next >= n here: a helper that starts now has nothing to take
+        call.done.wait(lk, [&] { return call.running == 0; });
     }
     if (call.status.load() != OMNI_OK) omni_set_error("omni_png_decode_batch: " + call.first_error);
     return call.status.load();

@@ -48,6 +48,18 @@ def _parse_cpulist(text):
     return cpus
 
 
+def _fmt_cpus(cpus):
+    """[0, 1, 2, 3, 8] -> '0-3,8'"""
+    out, run = [], []
+    for c in sorted(cpus) + [None]:
+        if run and (c is None or c != run[-1] + 1):
+            out.append(str(run[0]) if len(run) == 1 else f"{run[0]}-{run[-1]}")
+            run = []
+        if c is not None:
+            run.append(c)
+    return ",".join(out)
+
+
 def _gpu_local_cpus(index):
     """CPUs of the NUMA node the GPU `index` hangs off (sysfs `local_cpulist` of its PCI function), or None when unknown."""
     try:
@@ -69,6 +81,10 @@ def cpus_for_rank(local, nlocal, allowed, gpu_cpus=None):
     if not allowed or nlocal < 1:
         return set(allowed)
     mine = None
+    # the NUMA split only with COMPLETE topology: were some ranks to take chunks of their node and the others an even share of everything, the two
+    # kinds of chunk could overlap — and "launch threads never share a core" would no longer hold
+    if gpu_cpus is not None and (len(gpu_cpus) < nlocal or not all(gpu_cpus[j] and any(c in set(allowed) for c in gpu_cpus[j]) for j in range(nlocal))):
+        gpu_cpus = None
     if gpu_cpus is not None and local < len(gpu_cpus) and gpu_cpus[local]:
         mine = tuple(c for c in gpu_cpus[local] if c in set(allowed))
     if mine:
@@ -90,6 +106,11 @@ def bind_rank(local, nlocal):
         topo = [_gpu_local_cpus(j) for j in range(nlocal)] if torch.cuda.is_available() and torch.cuda.device_count() >= nlocal else None
         cpus = cpus_for_rank(local, nlocal, allowed, topo)
         os.sched_setaffinity(0, cpus)
+        # said once per rank: the narrowed set is also what png.effective_cpus(), PngBatches' workers and the decoder pool of this process now see
+        if os.environ.get("OMNI_BIND_QUIET", "0") == "0":
+            import sys
+            print(f"[omnifusion_amd.dist] local rank {local}/{nlocal} bound to {len(cpus)} of {len(allowed)} CPUs "
+                  f"({'NUMA-local' if topo and all(topo) else 'even split'}): {_fmt_cpus(cpus)}", file=sys.stderr, flush=True)
         return cpus
     except OSError:
         return None

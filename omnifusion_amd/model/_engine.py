@@ -161,20 +161,9 @@ class Engine:
         """sticky range flag of the split-half format on this engine's device (omni_sh_overflow); synchronises"""
         if self.device is None:
             return False
-        flag, viol = ctypes.c_int(0), ctypes.c_int(0)
+        flag = ctypes.c_int(0)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().omni_sh_overflow(ctypes.byref(flag), 1 if reset else 0), "sh_overflow")
-            if self.in_launch_reduce:                             # (experimental path only: its premise is checked by every block)
-                _lib.check(_lib.load().omni_conv_sk_status(ctypes.byref(viol), 1 if reset else 0), "conv_sk_status")
-        tmo = ctypes.c_int(0)
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.load().omni_transformer_status(ctypes.byref(tmo), 1 if reset else 0), "transformer_status")
-        if tmo.value:
-            raise RuntimeError("a block of the cooperative transformer kernel gave up waiting at a device-wide barrier (its 64 blocks were not co-resident "
-                               "for ~1 s): results since the last check are wrong — rerun with OMNI_COOP_TRANSFORMER=0")
-        if viol.value:
-            raise RuntimeError("a convolution block ran on another XCD than its block id implies: the in-launch split-K reduction hands partial tiles over "
-                               "through ONE XCD's L2 and its results may be wrong on this device / partition mode — rerun with OMNI_CONV_SK=0")
         return bool(flag.value)
 
     # ------------------------------------------------------------------ operator shims
@@ -199,10 +188,8 @@ class Engine:
                                                   _p(post), ctypes.c_size_t(post.numel()), self._s)
         elif self.sh:
             lat = 4 if (self._bs == 1 and self.latency_plan) else 0     # fmt bit 2: a lone panorama keeps the im2col tiles for 16-wide images
-            tk, ntk = self._sk_tickets(M * Ho * Wo, Cout, x.device) if (S > 1 and self.in_launch_reduce) else (None, 0)
-            rc = lib.omni_conv2d_sh_f16x3_sk_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), (0 if out_f32 else 1) | lat,
-                                                M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb),
-                                                _p(tk), ctypes.c_size_t(ntk), self._s)
+            rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), _p(x2), _p(self.w[key + ".w16"]), b, _p(res), _p(out), (0 if out_f32 else 1) | lat,
+                                             M, H, Wd, C1, C2, Cout, k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
         else:
             rc = lib.omni_conv2d_nhwc_f32_ws(_p(x), _p(x2), _p(self.w[key + ".w"]), b, _p(res), _p(out), M, H, Wd, C1, C2, Cout,
                                              k, k, stride, pad, act, S, _p(ws), ctypes.c_size_t(nb), self._s)
@@ -217,22 +204,6 @@ class Engine:
     latency_plan = True
     rows_gemm = True           # ... and its transformer GEMMs (18 rows) take the register-streaming kernel
 
-    # Split-K launches of the f16x3 path: 0 (default) two launches (partial sums + sh_splitk_reduce_kernel) | 1: the reduction INSIDE the launch
-    # (omni_conv2d_sh_f16x3_sk_ws; same plan, same bits) | 2: ... with the plan that sizes (tile, segment) units for the 256 CUs (omni_conv2d_sk_plan:
-    # other split factors, other bits).  Built for VERDICT r4 #1 and measured SLOWER on MI355X (profiles/r05a_sk_conv.txt): kept as a switch.
-    in_launch_reduce = int(os.environ.get("OMNI_IN_LAUNCH_REDUCE", "0"))
-
-    def _sk_tickets(self, rows, Cout, device):
-        """arrival counters of the in-launch split-K reduction: zero-initialised, left zero by every launch, one buffer per execution context
-        (= per stream); grown buffers keep their predecessors alive (a captured hipGraph may still point at them)"""
-        need = ((rows + 63) // 64) * (Cout // 32) + 8
-        tk = getattr(self, "_tk", None)
-        if tk is None or tk.numel() < need or tk.device != device:
-            if tk is not None:
-                self._tk_retired = getattr(self, "_tk_retired", []) + [tk]
-            self._tk = tk = torch.zeros(max(need, 16384), dtype=torch.int32, device=device)
-        return tk, tk.numel()
-
     def _splitk(self, rows, Cout, ksteps, device, shape=None):
         """Split factor planned for a NOMINAL batch (not the actual one), so that the K summation order — and with it
         every output bit — is the same whether a panorama is processed inside a batch of 2 or of 64 (image-sharded
@@ -243,17 +214,10 @@ class Engine:
         plan_batch = self.SINGLE_BATCH if (self._bs == 1 and self.latency_plan) else self.NOMINAL_BATCH
         rows_plan = rows // self._bs * plan_batch
         lib = _lib.load()
-        if self.sh and self.in_launch_reduce >= 2:                 # (tile, segment) units sized for the 256 CUs
-            KH, KW, stride, pad, H, W = shape if shape is not None else (1, 1, 1, 0, 1, 1)
-            S = int(lib.omni_conv2d_sk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps, KH, KW, stride, pad, H, W))
-        else:
-            S = int(lib.omni_conv2d_splitk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps))
+        S = int(lib.omni_conv2d_splitk_plan(ctypes.c_longlong(rows_plan), Cout, ksteps))
         if S <= 1:
             return 1, None, 0
-        if self.sh and self.in_launch_reduce:
-            ws, nb = self._workspace(int(lib.omni_conv2d_sk_ws_bytes(ctypes.c_longlong(rows), Cout, S)), device)
-        else:
-            ws, nb = self._workspace(S * rows * Cout * 4, device)
+        ws, nb = self._workspace(S * rows * Cout * 4, device)
         return S, ws, nb
 
     def _workspace(self, nbytes, device):
@@ -300,10 +264,9 @@ class Engine:
                                                    1 if out_sh else 0, rows, K, Nout, act, self._s), "gemm " + w16key)
             return out
         S, ws, nb = (1, None, 0) if K <= 512 else self._splitk(rows, Nout, K // 32, x.device)
-        tk, ntk = self._sk_tickets(rows, Nout, x.device) if (S > 1 and self.in_launch_reduce) else (None, 0)
-        rc = lib.omni_conv2d_sh_f16x3_sk_ws(_p(x), None, _p(self.w[w16key]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
-                                            (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws),
-                                            ctypes.c_size_t(nb), _p(tk), ctypes.c_size_t(ntk), self._s)
+        rc = lib.omni_conv2d_sh_f16x3_ws(_p(x), None, _p(self.w[w16key]), _p(self.w[bkey]) if bkey else None, _p(res), _p(out),
+                                         (1 if out_sh else 0) | 2, rows, 1, 1, K, 0, Nout, 1, 1, 1, 0, act, S, _p(ws),
+                                         ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "gemm " + w16key)
         return out
 
@@ -401,14 +364,7 @@ class Engine:
         d = self._conv(layer4, "down", M, P32, P32, 512, 32, 1, 1, 0, ACT_NONE, out_f32=True)
         tok = new(M, 512)
         _lib.check(lib.omni_token_pack_f32(_p(d), _p(self.w["pos"]), _p(tok), M, N, P32 * P32, 32, self._s), "token_pack")
-        coop = sh and self.coop_transformer and M <= self.COOP_MAX_ROWS and N <= 64
-        if coop:                                                     # the six layers + encoder_norm in ONE cooperative launch (csrc/omni_xformer.hip)
-            nb = int(lib.omni_transformer_scratch_bytes(M))
-            scratch, out_tok = new((nb + 3) // 4), new(M, 512)
-            _lib.check(lib.omni_transformer_sh_f16x3(_p(tok), self._xf_layers(), _p(self.w["enc_norm.w"]), _p(self.w["enc_norm.b"]), _p(out_tok),
-                                                     _p(scratch), ctypes.c_size_t(nb), _p(self._xf_sync(dev)), bs, N, self._s), "transformer")
-            tok = out_tok
-        for i in range(0 if coop else 6):
+        for i in range(6):
             t = f"t{i}."
             if sh:                                                   # LN / attention emit SH, the GEMMs run f16x3 from it
                 qkv = self._ln_gemm_sh(tok, t + "norm1.weight", t + "norm1.bias", 1e-5, t + "attn.qkv.w16", None, M, 1536)
@@ -427,8 +383,7 @@ class Engine:
             y = self._ln(tok, t + "norm2.weight", t + "norm2.bias", M, 1e-5)
             h = self._gemm(y, t + "mlp.fc1.weight", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU)
             tok = self._gemm(h, t + "mlp.fc2.weight", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
-        if not coop:
-            tok = self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
+        tok = self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
         _lib.check((lib.omni_add_hw_sh if sh else lib.omni_add_hw_f32)(_p(layer4), _p(tok), M, P32 * P32, 512, self._s), "token bias")
         # ---- decoder (:270-302); torch.cat is the two-source form of the conv
         up = self._up(layer4, M, P32, P32, 512, P16, P16)
@@ -464,36 +419,6 @@ class Engine:
     # de_conv4_0 and the two heads in one pass (omni_conv3x3_up2_heads_sh_f16x3): the decoder's last feature map is never written.  False: the two
     # kernels (fp32 heads; `Engine.last["de_conv4_0"]` then holds that map — the G6 check-point test reads it).  The outputs agree to ~1e-6 relative.
     fuse_heads = os.environ.get("OMNI_FUSE_HEADS", "1") != "0"
-
-    # Transformer_cascade as ONE cooperative launch (device-wide barriers between the phases, the next phase's weights in flight while a block waits) for
-    # batches of up to COOP_MAX_ROWS token rows; False (default) / larger: one launch per operator.  Per row the arithmetic of the lone-panorama kernels
-    # (omni_gemm_rows_*): a panorama's bits are those of its own single-panorama forward's transformer, in any batch.  Built for VERDICT r4 #6 and measured
-    # SLOWER than the per-operator launches (0.954 -> 1.087 ms for one panorama, 2.42 -> 2.76 ms at 8; profiles/r05b_coop_transformer.txt): off.
-    coop_transformer = os.environ.get("OMNI_COOP_TRANSFORMER", "0") != "0"
-    COOP_MAX_ROWS = 256
-
-    def _xf_layers(self):
-        """the six layer records of omni_transformer_sh_f16x3 (device pointers; the fragment-ordered weight copies are made on first use)"""
-        recs = getattr(self, "_xf_recs", None)
-        if recs is None or getattr(self, "_xf_recs_w", None) is not self.w:
-            class Rec(ctypes.Structure):
-                _fields_ = [(n, ctypes.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "proj_b", "fc1_b", "fc2_b", "qkv_w16r", "proj_w16r", "fc1_w16r", "fc2_w16r")]
-            recs = (Rec * 6)()
-            for i in range(6):
-                t = f"t{i}."
-                ptr = lambda k: self.w[t + k].data_ptr()
-                recs[i] = Rec(ptr("norm1.weight"), ptr("norm1.bias"), ptr("norm2.weight"), ptr("norm2.bias"), ptr("attn.proj.bias"), ptr("mlp.fc1.bias"), ptr("mlp.fc2.bias"),
-                              self._rows_weights(t + "attn.qkv.w16", 1536, 512).data_ptr(), self._rows_weights(t + "attn.proj.w16", 512, 512).data_ptr(),
-                              self._rows_weights(t + "mlp.fc1.w16", 2048, 512).data_ptr(), self._rows_weights(t + "mlp.fc2.w16", 512, 2048).data_ptr())
-            self._xf_recs, self._xf_recs_w = recs, self.w
-        return recs
-
-    def _xf_sync(self, device):
-        """the cooperative kernel's two counters: zero-initialised, left zero by every launch; one pair per execution context (stream)"""
-        sy = getattr(self, "_xf_sy", None)
-        if sy is None or sy.device != device:
-            self._xf_sy = sy = torch.zeros(2, dtype=torch.int32, device=device)
-        return sy
 
     # Passes of a few panoramas through the widest stages (same kernels, same bits) were worth +1.3 % with three forwards in flight while the
     # up-sampled tensors still went through HBM; since the up-sampling is computed inside the convolution (fuse_up) they change nothing

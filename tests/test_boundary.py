@@ -128,28 +128,13 @@ def test_isa_guard_no_packed_fp32_and_no_scratch_in_counted_wait_kernels(tmp_pat
 
 
 def test_round5_host_side_entry_points():
-    """The host-only halves of the round-5 entry points (no GPU): the split plan for the in-launch reduction is batch-independent by construction (the
-    caller passes NOMINAL rows) and never splits what a halo kernel takes unsplit; workspace / scratch sizes; the heads' weights in fragment order
+    """The host-only halves of the round-5 entry points (no GPU): scratch sizes; the heads' weights in fragment order
     (omni_heads_pack_f16x3) against a plain restatement of the layout conv3x3_up2_g1_kernel<HEADS> reads."""
     import numpy as np
     from omnifusion_amd import _lib
     L = _lib.load()
     ll = ctypes.c_longlong
-    # layer3 at 8 panoramas: tile kernel, 72 K-steps; layer1 (32 x 32 images): halo kernel, stays unsplit; too few K-steps: unsplit
-    s3 = L.omni_conv2d_sk_plan(ll(144 * 64), 256, 72, 3, 3, 1, 1, 8, 8)
-    assert 1 <= s3 <= 18 and L.omni_conv2d_sk_plan(ll(144 * 1024), 64, 18, 3, 3, 1, 1, 32, 32) == 1
-    assert L.omni_conv2d_sk_plan(ll(144 * 64), 256, 4, 1, 1, 2, 0, 16, 16) == L.omni_conv2d_splitk_plan(ll(144 * 64), 256, 4)
-    _lib.set_option("conv_sk_plan", 0)
-    try:
-        assert L.omni_conv2d_sk_plan(ll(144 * 16), 512, 144, 3, 3, 1, 1, 4, 4) == L.omni_conv2d_splitk_plan(ll(144 * 16), 512, 144)
-    finally:
-        _lib.set_option("conv_sk_plan", 1)
-    for rows, cout, S in ((9216, 256, 3), (2304, 512, 7), (144, 512, 16), (19 * 64, 64, 2)):
-        nb = L.omni_conv2d_sk_ws_bytes(ll(rows), cout, S)
-        assert nb >= S * rows * cout * 4 and nb % 4 == 0
-    assert L.omni_conv2d_sk_ws_bytes(ll(9216), 256, 1) == 0
     assert L.omni_up2_heads_scratch_bytes(144, 128) == 144 * 32 * 4 * 4 * 6 * 36 * 4 and L.omni_up2_heads_scratch_bytes(3, 100) == 0
-    assert L.omni_transformer_scratch_bytes(144) == 144 * (1536 + 512 + 2048) * 4 and L.omni_transformer_scratch_bytes(0) == 0
     # heads pack: row r of the extra matrix product = (register group g = r >> 3, output lane half hh = (r >> 2) & 1, dx = (r & 3) - 1) -> (dy, head) pair g + 3 hh;
     # element e of k chunk kc in k group h = channel 16 kc + 8 (e >> 2) + 4 h + (e & 3); [hi kc0 | hi kc1 | lo kc0 | lo kc1][lane = r + 32 h][8] halfs
     w = np.random.default_rng(3).standard_normal((2, 9, 32)).astype(np.float32)

@@ -664,122 +664,6 @@ def test_module_moves_and_dataparallel_wrapper():
     assert torch.equal(inner(torch.from_numpy(g["rgb"]).to(DEV)), out)
 
 
-@pytest.mark.parametrize("cfg", [
-    # M, H, W, C1, C2, Cout, k, stride, act, res, fmt     (fmt bit 0: SH output, bit 1: fp32 residual)
-    (144, 8, 8, 256, 0, 256, 3, 1, 1, True, 1),            # a layer3 convolution at 8 panoramas (128 x 128 tiles, loader waves)
-    (72, 8, 8, 256, 0, 256, 3, 1, 1, True, 1),             # ... at 4 (a half-batch lane)
-    (144, 4, 4, 512, 0, 512, 3, 1, 1, True, 1),            # layer4
-    (144, 8, 8, 256, 256, 128, 3, 1, 1, False, 1),         # de_conv0_1: two sources
-    (36, 16, 16, 128, 0, 256, 3, 2, 1, False, 1),          # a stride-2 convolution
-    (144, 1, 1, 2048, 0, 512, 1, 1, 0, True, 2),           # fc2: fp32 output, fp32 residual
-    (18, 1, 1, 2048, 0, 512, 1, 1, 0, True, 2),            # ... of a lone panorama (ragged row tile)
-    (144, 4, 4, 512, 0, 32, 1, 1, 0, False, 0),            # down: 32 output channels, fp32 output
-    (19, 8, 8, 64, 0, 64, 3, 1, 2, False, 1),              # rows not a multiple of the tile, GELU
-])
-def test_in_launch_splitk_reduction_equals_two_launch_form(cfg):
-    """omni_conv2d_sh_f16x3_sk_ws reduces a split-K convolution INSIDE the launch — (tile, segment) units, all segments of a tile on one
-    XCD, partial tiles through that XCD's L2, the last arrival sums them in segment order — and must give the BITS of the two-launch form
-    (partial sums to the workspace + sh_splitk_reduce_kernel) for every split factor and tile shape, launch after launch (a lost hand-over would
-    show as a stale tile) and leave its arrival counters zero.  (Experimental path, option conv_sk = 1.)"""
-    L, lib = _lib()
-    from omnifusion_amd.model._engine import split_weights_f16x3
-    M, H, W, C1, C2, Cout, k, s, act, use_res, fmt = cfg
-    pad = k // 2
-    g = torch.Generator().manual_seed(11)
-    d = lambda t: t.contiguous().to(DEV)
-    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
-    rows, ksteps = M * Ho * Wo, k * k * (C1 + C2) // 32
-    n32 = lambda t: ctypes.c_size_t(t.numel())
-
-    def to_sh(t):
-        o = torch.empty_like(t)
-        assert lib.omni_sh_from_f32(_p(t), _p(o), n32(t), _stream()) == 0
-        return o
-    X1 = to_sh(d(torch.randn(M, H, W, C1, generator=g)))
-    X2 = to_sh(d(torch.randn(M, H, W, C2, generator=g))) if C2 else None
-    W16 = split_weights_f16x3(torch.randn(Cout, (C1 + C2) * k * k, generator=g) / np.sqrt((C1 + C2) * k * k)).to(DEV)
-    B = d(torch.randn(Cout, generator=g))
-    R = d(torch.randn(M, Ho, Wo, Cout, generator=g)) if use_res else None
-    if R is not None and not (fmt & 2):
-        R = to_sh(R)
-    tickets = torch.zeros(((rows + 63) // 64) * (Cout // 32) + 8, dtype=torch.int32, device=DEV)
-    flag = ctypes.c_int(0)
-    assert lib.omni_conv_sk_status(ctypes.byref(flag), 1) == 0
-    L.set_option("conv_sk", 1)                                                     # (off by default: measured slower, one stream only — profiles/r05a_sk_conv.txt)
-    try:
-        for tile in (-1, 0, 3, 4, 9):
-            L.set_option("conv_sh_tile", tile)
-            for S in sorted({2, 3, min(7, ksteps // 4), int(lib.omni_conv2d_sk_plan(ctypes.c_longlong(rows), Cout, ksteps, k, k, s, pad, H, W))} - {0, 1}):
-                nb = int(lib.omni_conv2d_sk_ws_bytes(ctypes.c_longlong(rows), Cout, S))
-                assert nb >= S * rows * Cout * 4
-                ws = torch.empty(nb // 4, device=DEV)
-                two = torch.empty((M, Ho, Wo, Cout), device=DEV)
-                rc = lib.omni_conv2d_sh_f16x3_ws(_p(X1), _p(X2), _p(W16), _p(B), _p(R), _p(two), fmt, M, H, W, C1, C2, Cout, k, k, s, pad, act,
-                                                 S, _p(ws), ctypes.c_size_t(nb), _stream())
-                assert rc == 0, lib.omni_last_error()
-                for rep in range(4):
-                    one = torch.full_like(two, float("nan"))
-                    ws.fill_(float("nan"))                                         # nothing may be read that this launch did not write
-                    rc = lib.omni_conv2d_sh_f16x3_sk_ws(_p(X1), _p(X2), _p(W16), _p(B), _p(R), _p(one), fmt, M, H, W, C1, C2, Cout, k, k, s, pad, act,
-                                                        S, _p(ws), ctypes.c_size_t(nb), _p(tickets), ctypes.c_size_t(tickets.numel()), _stream())
-                    assert rc == 0, lib.omni_last_error()
-                    assert torch.equal(one, two), (tile, S, rep, (one - two).abs().max().item())
-                assert int(tickets.abs().sum()) == 0, (tile, S)
-        # without tickets / with a too small workspace the same entry point runs the two-launch form
-        ws = torch.empty(2 * rows * Cout, device=DEV)
-        o = torch.empty((M, Ho, Wo, Cout), device=DEV)
-        assert lib.omni_conv2d_sh_f16x3_sk_ws(_p(X1), _p(X2), _p(W16), _p(B), _p(R), _p(o), fmt, M, H, W, C1, C2, Cout, k, k, s, pad, act,
-                                              2, _p(ws), ctypes.c_size_t(ws.numel() * 4), None, ctypes.c_size_t(0), _stream()) == 0
-    finally:
-        L.set_option("conv_sh_tile", -1)
-        L.set_option("conv_sk", 0)
-    # The premise "block b runs on XCD b % 8" is CHECKED by every block (XCC_ID) and reported, not assumed: alone in a fresh process it held for every
-    # launch of this test; inside the whole suite (other streams created before) and with two lanes in flight it does not — the results above were
-    # bit-identical either way on MI355X, but nothing guarantees that: one more reason the path is off by default (profiles/r05a_sk_conv.txt).
-    assert lib.omni_conv_sk_status(ctypes.byref(flag), 1) == 0
-    print("in-launch reduction: block-on-unexpected-XCD flag =", flag.value)
-
-
-def test_cooperative_transformer_gives_the_bits_of_the_per_operator_kernels():
-    """csrc/omni_xformer.hip: Transformer_cascade (model/spherical_model.py:169-187, blocks.py:14-89) in ONE cooperative launch — device-wide barriers
-    between the phases — must reproduce the per-operator path: bit for bit for a lone panorama (whose forward runs exactly the kernels the phases are made
-    of: omni_gemm_rows_ln_sh / attention / gemm_rows), to fp32 summation order for a batch (whose per-operator path uses the tile kernels), for 18 and 46
-    tokens, also with several such grids in flight (pipelined forwards), and never time out at a barrier."""
-    from omnifusion_amd.model._engine import Engine
-    spherical_fusion, spherical_fusion_it, make_state_dict = _nets()
-    net = spherical_fusion(4, 18, (128, 128), (80, 80)).cuda()
-    net.load_state_dict(make_state_dict(42, 18, False))
-    rgb = torch.rand((5, 3, 64, 128), generator=torch.Generator().manual_seed(3)).to(DEV)
-    net6 = spherical_fusion_it(6, 46, (128, 128), (80, 80)).cuda()
-    net6.load_state_dict(make_state_dict(42, 46, True))
-    rgb6 = torch.rand((2, 3, 64, 128), generator=torch.Generator().manual_seed(4)).to(DEV)
-    assert not Engine.coop_transformer                                        # (off by default: measured slower, profiles/r05b_coop_transformer.txt)
-    ref1, ref5 = net(rgb[:1]).clone(), net(rgb).clone()
-    ref6 = [o.clone() for o in net6(rgb6[:1], iter=2)]
-    ref6b = [o.clone() for o in net6(rgb6, iter=2)]
-    try:
-        Engine.coop_transformer = True
-        _coop_checks(net, net6, rgb, rgb6, ref1, ref5, ref6, ref6b)
-    finally:
-        Engine.coop_transformer = False
-
-
-def _coop_checks(net, net6, rgb, rgb6, ref1, ref5, ref6, ref6b):
-    for rep in range(3):
-        assert torch.equal(net(rgb[:1]), ref1)                               # a lone panorama: the same kernels' arithmetic, the same bits
-        out5 = net(rgb)
-        assert (out5 - ref5).abs().max().item() <= 2e-5
-        assert torch.equal(net(rgb[1:4]), out5[1:4])                          # ... and a panorama's bits do not depend on its batch
-    o6 = net6(rgb6[:1], iter=2)                                               # 46 tokens = two row tiles (the per-operator path takes the tile kernels there), two iterations
-    assert max((a - b).abs().max().item() for a, b in zip(o6, ref6)) <= 2e-5
-    o6b = net6(rgb6, iter=2)
-    assert max((a - b).abs().max().item() for a, b in zip(o6b, ref6b)) <= 2e-5
-    run = net.pipelined(3)                                                    # three cooperative grids in flight
-    pend = [run(rgb) for _ in range(9)]
-    assert all(torch.equal(p.get(), out5) for p in pend)
-    assert not net.overflowed() and not net6.overflowed()                     # (raises if a barrier ever timed out)
-
-
 def test_dataparallel_over_several_replicas_in_one_process():
     """test.py:105-111 on a multi-GPU node: `nn.DataParallel(network)` scatters the batch over replica THREADS.  device_ids=[0, 0]
     drives exactly that code path on one GPU (scatter -> replicate -> parallel_apply on two threads -> gather): the replicas run on

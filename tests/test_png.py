@@ -362,3 +362,161 @@ def test_row_kernels_every_pixel_size(ctype, depth):
                 assert np.array_equal(png.imread(f), want), (ctype, depth, W, rot)
                 if ctype == 0:
                     assert np.array_equal(png.imread(f, unchanged=True), a[:, :, 0]), (depth, W, rot)
+
+
+def test_decode_batch_works_in_a_forked_child_and_beside_a_busy_pool():
+    """the decoder pool is process-wide; torch DataLoader workers (the reference's test.py:90-97) are FORKED children that inherit the
+    pool object but none of its threads — a batch call in the child queued helpers nobody ran and waited for ever.  The pool is now abandoned across
+    fork() (pthread_atfork holds its locks over the fork, the child starts its own pool on first use), and a caller no longer waits for helpers that
+    never started.  The child must decode the same bytes as the parent, several times, within seconds."""
+    import os
+    import threading
+    frames = [RNG.integers(0, 256, (48, 96, 3), dtype=np.uint8) for _ in range(12)]
+    files = [encode_png(f, 2, 8, idat=2) for f in frames]
+    want = png.decode_batch(files, threads=0).numpy().copy()                       # the parent's pool exists and has run
+    busy = threading.Event()
+
+    def hammer():                                                                  # the pool is busy (and its locks are taken and released) while the child forks
+        while not busy.is_set():
+            png.decode_batch(files, threads=0)
+    th = [threading.Thread(target=hammer) for _ in range(3)]
+    for t in th:
+        t.start()
+    try:
+        for rep in range(3):
+            r, w = os.pipe()
+            pid = os.fork()
+            if pid == 0:                                                           # the child: no pytest machinery, just the library
+                code = 1
+                try:
+                    os.close(r)
+                    ok = all(np.array_equal(png.decode_batch(files, threads=0).numpy(), want) for _ in range(5))
+                    ok = ok and np.array_equal(png.decode_batch(files, threads=4).numpy(), want)
+                    os.write(w, b"ok" if ok else b"no")
+                    code = 0
+                finally:
+                    os._exit(code)
+            os.close(w)
+            done = threading.Event()
+            got = []
+
+            def reader():
+                got.append(os.read(r, 2)); done.set()
+            rt = threading.Thread(target=reader, daemon=True)
+            rt.start()
+            finished = done.wait(60)
+            if not finished:
+                os.kill(pid, 9)
+            os.waitpid(pid, 0)
+            os.close(r)
+            assert finished, "the forked child hung in omni_png_decode_batch"
+            assert got == [b"ok"], got
+    finally:
+        busy.set()
+        for t in th:
+            t.join()
+    assert np.array_equal(png.decode_batch(files, threads=0).numpy(), want)       # ... and the parent's pool is intact
+
+
+def _bits_writer():
+    out, acc, n = bytearray(), 0, 0
+
+    def put(v, k):                                                                 # k bits, LSB first (header fields, extra bits)
+        nonlocal acc, n
+        acc |= v << n; n += k
+        while n >= 8:
+            out.append(acc & 255); acc >>= 8; n -= 8
+
+    def code(c, k):                                                                # a Huffman code: MSB first
+        put(int(format(c, "0%db" % k)[::-1], 2), k)
+
+    def flush():
+        nonlocal acc, n
+        if n:
+            out.append(acc & 255); acc = 0; n = 0
+        return bytes(out)
+    return put, code, flush
+
+
+def _canonical(lengths):
+    """RFC 1951 3.2.2: symbol -> (code, length)"""
+    bl = {}
+    for l in lengths:
+        if l:
+            bl[l] = bl.get(l, 0) + 1
+    code, nxt = 0, {}
+    for bits in range(1, 16):
+        code = (code + bl.get(bits - 1, 0)) << 1
+        nxt[bits] = code
+    out = {}
+    for s, l in enumerate(lengths):
+        if l:
+            out[s] = (nxt[l], l); nxt[l] += 1
+    return out
+
+
+def test_hand_built_streams_15_bit_codes_and_distance_32768():
+    """the differential fuzz's payloads are small; the corners zlib's own encoder hardly ever emits are built by hand here — a dynamic
+    block whose literal / length codes are 15 bits long (behind the second-level tables) and whose matches reach back the full 32768 bytes with length
+    258 — and a multi-megabyte photo-like stream; all checked against Python's zlib."""
+    r = np.random.default_rng(21)
+    # literal/length alphabet: 0..255 + 256 + 257..285 (286 symbols); a Kraft-complete length set with many 15-bit codes:
+    # 2 symbols of length 2 would dominate; use: one symbol of length 1 (literal 0x41), then a chain 2,3,...,14 for 13 symbols and the rest of the budget at 15
+    ll = [0] * 286
+    ll[0x41] = 1
+    chain = [256, 285, 0x42, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x4b, 0x4c]     # lengths 2..14
+    for k, sym in enumerate(chain):
+        ll[sym] = 2 + k
+    rest = [s for s in (list(range(0x50, 0x50 + 3)) + [257]) if ll[s] == 0]                    # remaining Kraft budget 2^-14 = two codes of length 15 ... use 15-bit codes
+    # budget left after 1/2 + sum_{l=2..14} 2^-l = 1 - 2^-14 -> exactly two 15-bit codes
+    ll[rest[0]] = 15; ll[rest[1]] = 15
+    dl = [0] * 30
+    dl[29] = 1; dl[0] = 1                                                          # distance codes: 29 (24577..32768, 13 extra bits) and 0 (distance 1)
+    lit, dist = _canonical(ll), _canonical(dl)
+    # code-length alphabet: we need to transmit lengths {0,1,2..15}: give every code-length symbol 0..15 a 4-bit code (16 symbols x 2^-4 = 1), 16/17/18 unused
+    cl = [4] * 16 + [0, 0, 0]
+    clc = _canonical(cl)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    put, code, flush = _bits_writer()
+    put(1, 1); put(2, 2)                                                           # BFINAL, dynamic
+    put(286 - 257, 5); put(30 - 1, 5); put(19 - 4, 4)
+    for s in order:
+        put(cl[s], 3)
+    for l in ll + dl:
+        code(*clc[l])
+    plain = bytearray()
+
+    def literal(b):
+        code(*lit[b]); plain.append(b)
+    window = bytes(r.choice([0x41, 0x42, 0x43, 0x50, 0x51], 32768, p=[.6, .2, .1, .05, .05]).astype(np.uint8))
+    for b in window:
+        literal(b)
+    for _ in range(40):                                                            # length 258 (symbol 285, no extra bits) at distance 32768 (code 29 + 13 extra bits all ones)
+        code(*lit[285]); code(*dist[29]); put(8191, 13)
+        start = len(plain) - 32768
+        for k in range(258):
+            plain.append(plain[start + k])
+        literal(0x50); literal(0x51)                                               # the two 15-bit literals between the matches
+        code(*lit[285]); code(*dist[0])                                            # distance 1, length 258: a run
+        for k in range(258):
+            plain.append(plain[-1])
+    code(*lit[256])
+    deflate = flush()
+    z = b"\x78\x01" + deflate + struct.pack(">I", zlib.adler32(bytes(plain)))
+    assert zlib.decompress(z) == bytes(plain)                                      # the hand-built stream is valid by an independent decoder
+    rc, o, used = _inflate(z, len(plain))
+    assert rc == 0 and o == bytes(plain) and used == len(z)
+    rc, o, _ = _inflate(z, len(plain) - 1)
+    assert rc != 0
+    # photo-like, several megabytes (a real panorama inflates to 1.5-25 MB): smooth gradients + noise through the Paeth filter of the encoder above, and as a raw stream
+    h, w = 768, 1536
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (np.stack([xx * 0.11 + yy * 0.07, xx * 0.05 - yy * 0.09, (xx + yy) * 0.03], 2) + r.normal(0, 6, (h, w, 3))).astype(np.int64) % 256
+    img = img.astype(np.uint8)
+    f = encode_png(img, 2, 8, filters=(4,), idat=5)
+    assert np.array_equal(png.imread(f), img[:, :, ::-1])
+    raw = img.tobytes() * 2                                                        # 7 MB, the second half a 3.5-MB-distant repeat (no match reaches it: fresh codes again)
+    for lvl in (1, 6):
+        zz = zlib.compress(raw, lvl)
+        rc, o, used = _inflate(zz, len(raw))
+        assert rc == 0 and o == raw and used == len(zz)

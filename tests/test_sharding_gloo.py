@@ -51,9 +51,13 @@ def test_rank_cpu_binding_follows_the_gpu_topology():
     assert all(sets[a].isdisjoint(sets[b]) for a in range(8) for b in range(a + 1, 8))
     even = [dist.cpus_for_rank(r, 8, allowed, None) for r in range(8)]
     assert even[0] == set(range(8)) and even[7] == set(range(56, 64))
-    # a cgroup that allows only part of a node; a GPU with unknown locality falls back to the even split
+    # PARTIAL topology (one GPU of unknown locality): every rank takes the even split — a node chunk beside an even share would overlap
     part = [dist.cpus_for_rank(r, 2, set(range(4, 12)), [list(range(0, 16)), None]) for r in range(2)]
-    assert part[0] == set(range(4, 12)) and part[1] == set(range(8, 12))
+    assert part[0] == set(range(4, 8)) and part[1] == set(range(8, 12))
+    # a cgroup that allows only part of a node: the node's ranks share what is allowed of it
+    cg = [dist.cpus_for_rank(r, 2, set(range(4, 12)), [list(range(0, 16)), list(range(0, 16))]) for r in range(2)]
+    assert cg[0] == set(range(4, 8)) and cg[1] == set(range(8, 12))
+    assert dist._fmt_cpus({0, 1, 2, 3, 8, 10, 11}) == "0-3,8,10-11"
     assert dist.cpus_for_rank(5, 8, {3}, None) == {3} and dist.cpus_for_rank(2, 4, {0, 1}, None) != set()
     assert dist._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
 

@@ -1,7 +1,7 @@
 // Differential fuzz of csrc/omni_inflate.h against libz under the sanitizers (exact-size heap buffers: any access outside them is reported):
 //   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -std=c++20 tools/inflate_fuzz.cpp -lz -o /tmp/inflate_fuzz && /tmp/inflate_fuzz <seed> <iterations>
 // random payloads of four kinds at zlib levels 0-9, intact / truncated / 1-3 flipped bits, destination exact / short / long: accept and refuse as libz, same bytes.
-// (round 5: 4 seeds x 30 000 iterations clean)
+// (round 5: 4 seeds x 30 000 iterations clean; round 6: payloads to 4 MB and a photo-like generator, 2 seeds x 4 000 clean)
 #include "../omnifusion_amd/csrc/omni_inflate.h"
 #include <zlib.h>
 #include <stdio.h>
@@ -14,12 +14,17 @@ int main(int argc, char** argv)
     long ok = 0, bad = 0, agree = 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 20000;
     for (int it = 0; it < iters; ++it) {
-        const size_t n = rng() % 5000 + 1;
+        // sizes: mostly small (every boundary of the fast loop is near), 1 in 8 up to 400 KB (match distances to 32 KiB, long codes behind the second-level
+        // tables, long runs inside the fast loop: ADVICE r5), 1 in 64 a few MB (a real panorama inflates to 1.5-25 MB)
+        const unsigned pick = (unsigned)(rng() % 64);
+        const size_t n = pick == 0 ? rng() % 4000000 + 1 : (pick < 9 ? rng() % 400000 + 1 : rng() % 5000 + 1);
         std::vector<unsigned char> d(n);
-        const int mode = rng() % 4;
+        const int mode = rng() % 5;
         unsigned char v = 0;
+        const size_t rowlen = 3 * (64 + rng() % 2000);           // mode 4: photo-like — a smooth gradient + noise, rows that resemble the row above
         for (size_t i = 0; i < n; ++i) {
             if (mode == 0) d[i] = (unsigned char)rng();
+            else if (mode == 4) d[i] = (unsigned char)((i >= rowlen ? d[i - rowlen] : (unsigned char)(i / 7)) + (int)(rng() % 9) - 4 + ((rng() & 63) == 0 ? (int)(rng() % 64) : 0));
             else if (mode == 1) d[i] = (unsigned char)(rng() % 4);
             else if (mode == 2) { v = (unsigned char)(v + (int)(rng() % 5) - 2); d[i] = v; }
             else d[i] = (unsigned char)((i % 7) ? 0 : (rng() & 1 ? 255 : 1));

@@ -40,6 +40,9 @@
 #define OMNI_CONV_ABL 0
 #endif
 #define OMNI_ABL(bit) ((OMNI_CONV_ABL & (bit)) != 0)
+#ifndef OMNI_PP_PRIO
+#define OMNI_PP_PRIO 0                                         // conv_sh_kernel<.., PP>: s_setprio 1 around a phase's matrix instructions
+#endif
 #ifndef OMNI_G1_PW
 #define OMNI_G1_PW 4                                           // producer waves of conv3x3_up2_g1_kernel<HEADS> (8: measured equal)
 #endif
@@ -266,9 +269,21 @@ __device__ __forceinline__ void splitk_finish(f4v v, size_t o, const float* __re
 // NL > 0: NL extra LOADER waves issue every LDS-DMA piece of the block and wait for them; the WM x WN matrix waves never touch vector memory
 // inside the K loop (a piece costs the issuing wave 100-185 cycles between matrix instructions: four pieces per K-step against twelve
 // matrix instructions of 32).  Same pieces, same LDS image, same K order: same bits.
-template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>           // NST stages in flight (the step loop is unrolled by it)
+//
+// PP ("ping-pong", round 6; needs loader waves and 8 matrix waves): the two matrix waves of a SIMD (waves w and w + 4: a block's waves go to the four SIMDs
+// in turn) run in ANTI-PHASE.  With one barrier per K-step all eight matrix waves start their fragment reads together — nobody has operands, the matrix
+// pipes idle ~350 cycles — and then the two waves of a SIMD run their 12 matrix instructions one after the other: 1 150 cycles per step for 768 of
+// matrix work (tools/tile_stamps.py, profiles/r05j_halo_stamps.txt).  Here a K-step is TWO phases behind two barriers: in phase a_k group A (waves 0-3)
+// issues its 12 matrix instructions of step k while group B (waves 4-7) reads its fragments of step k; in phase b_k B computes step k and A reads step
+// k+1.  Every SIMD's matrix pipe has work in every phase, the LDS port serves four waves' reads (48 KiB) under 384 cycles of matrix work.
+//      group A:  b_{k-1} | reads(k)  wait | a_k | mfma(k)          | b_k | reads(k+1) ...
+//      group B:  b_{k-1} | mfma(k-1)      | a_k | reads(k)   wait  | b_k | mfma(k)    ...
+//      loaders:  wait(stage k landed) | b_{k-1} | issue stage k+NST-1 -> the slot of stage k-1 (B's reads of it ended in front of b_{k-1}) | a_k | ...
+// Same pieces, same LDS image, same fragments, same order of the matrix instructions on every accumulator: same bits.
+template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0, bool PP = false>           // NST stages in flight (the step loop is unrolled by it)
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs a)
 {
+    static_assert(!PP || (NL > 0 && WM * WN == 8 && NST >= 3), "ping-pong: eight matrix waves (two per SIMD) + loader waves, three stages");
     constexpr int NW = WM * WN, LW = NL > 0 ? NL : NW, RPP = 8 * LW;   // matrix waves; waves that issue DMA; tile rows covered by one DMA pass of the block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
     constexpr int APASS = BM / RPP, BPASS = BN / RPP, LPS = APASS + BPASS;
@@ -354,7 +369,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
         f_ky = f_tap / a.KW; f_kx = f_tap - f_ky * a.KW;
         refresh();
     };
-    auto issue = [&](int ks, auto slot_c) {
+    // (a stage's pieces in two parts — the pixel operand, then the weights and the step to the next (tap, source, group) — so that the ping-pong schedule
+    //  can spread them over its two phases: 32 KiB per K-step through the CU's address path take ~500 cycles, more than one phase's 384 of matrix work)
+    auto issue_a = [&](auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         unsigned char* sb = lds + SLOT * STAGE + iw * 1024;
         const int so = f_gl * 128;
@@ -366,6 +383,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
 #pragma unroll
             for (int i = 0; i < APASS; ++i) dma16(rs1, sb + i * (1024 * LW), voff[i], so);
         }
+    };
+    auto issue_b = [&](int ks, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        unsigned char* sb = lds + SLOT * STAGE + iw * 1024;
         if (!OMNI_ABL(128)) {
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) dma16(rsw, sb + A_BYTES + i * (1024 * LW), wbase[i], ks * 128);
@@ -377,6 +398,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
             refresh();
         }
     };
+    auto issue = [&](int ks, auto slot_c) { issue_a(slot_c); issue_b(ks, slot_c); };
 
     f16v acc[TM][TN], acc1[TM][TN];                              // acc = hi.hi, acc1 = hi.lo + lo.hi (scaled by 2^11)
 #pragma unroll
@@ -408,7 +430,40 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
             ((ks_begin + S < ks_end ? issue(ks_begin + S, std::integral_constant<int, S>()) : (void)0), ...);
         }(std::make_integer_sequence<int, NST - 1>());
     }
+    auto pbarrier = [&]() {                                      // a phase boundary of the ping-pong schedule: nothing moves across it
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
     if (loader) {
+        if constexpr (PP) {
+            auto lstep = [&](int ks, auto slot_c) {
+                constexpr int SLOT = decltype(slot_c)::value;
+                const int sk_ = 128 + 4 * (ks - ks_begin);
+                if (wave == NW && ks - ks_begin < 28) cstamp(sk_);
+                if (ks + NST - 2 < ks_end) wait_vm<(NST - 2) * LPS>();
+                else                       wait_vm<0>();
+                if (wave == NW && ks - ks_begin < 28) cstamp(sk_ + 1);
+                pbarrier();                                       // b_{k-1}: stage ks has landed for everybody; group B is done with stage ks-1
+                if (wave == NW && ks - ks_begin < 28) cstamp(sk_ + 2);
+                if (ks + NST - 1 < ks_end) issue_a(std::integral_constant<int, (SLOT + NST - 1) % NST>());             // half of the pieces in each phase
+                if (wave == NW && ks - ks_begin < 28) cstamp(sk_ + 3);
+                pbarrier();                                       // a_k
+                if (ks + NST - 1 < ks_end) issue_b(ks + NST - 1, std::integral_constant<int, (SLOT + NST - 1) % NST>());
+            };
+            int ks = ks_begin;
+            for (; ks + NST - 1 < ks_end; ks += NST) {
+                [&]<int... S>(std::integer_sequence<int, S...>) { (lstep(ks + S, std::integral_constant<int, S>()), ...); }
+                (std::make_integer_sequence<int, NST>());
+            }
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                ((ks + S < ks_end ? lstep(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
+            }(std::make_integer_sequence<int, NST - 1>());
+            pbarrier();                                           // b_{n-1}
+            if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) __syncthreads();    // (the barrier in front of the LDS epilogue)
+            return;
+        }
         // ---- a loader wave's K loop: my pieces of stage ks have landed -> barrier (everybody's have; the matrix waves are done with stage
         // ks-1) -> the pieces of stage ks+NST-1 into the slot stage ks-1 occupied
         auto lstep = [&](int ks, auto slot_c) {
@@ -436,6 +491,78 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
         return;
     }
 
+    if constexpr (PP) {
+        const bool grp_b = wave >= NW / 2;                           // (wave-uniform) waves w and w + NW/2 share a SIMD
+        h8v ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        auto reads = [&](auto slot_c) {
+            constexpr int SLOT = decltype(slot_c)::value;
+            const unsigned char* sl = lds + SLOT * STAGE;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[kc][i] = *reinterpret_cast<const h8v*>(sl + i * 4096 + foa[kc]);
+                    al[kc][i] = *reinterpret_cast<const h8v*>(sl + i * 4096 + foa[2 + kc]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[kc][j] = *reinterpret_cast<const h8v*>(sl + j * 4096 + fob[kc]);
+                    bl[kc][j] = *reinterpret_cast<const h8v*>(sl + j * 4096 + fob[2 + kc]);
+                }
+            }
+            wait_lds_reads();                                        // the fragments are in registers before the phase ends (the buffer may be refilled two phases later)
+        };
+        auto mfmas = [&]() {
+            if constexpr (OMNI_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], ah[kc][i], acc[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kc][j], ah[kc][i], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kc][j], al[kc][i], acc1[i][j], 0, 0, 0);
+                    }
+            if constexpr (OMNI_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+        };
+        pbarrier();                                                  // b_{-1}: stage ks_begin has landed
+        if (!grp_b) {
+            auto stepa = [&](int ks, auto slot_c) {
+                if (wave == 0 && ks - ks_begin < 28) cstamp(8 + 4 * (ks - ks_begin));
+                reads(slot_c);
+                if (wave == 0 && ks - ks_begin < 28) cstamp(11 + 4 * (ks - ks_begin));
+                pbarrier();                                          // a_k
+                if (wave == 0 && ks - ks_begin < 28) cstamp(9 + 4 * (ks - ks_begin));
+                mfmas();
+                if (wave == 0 && ks - ks_begin < 28) cstamp(10 + 4 * (ks - ks_begin));
+                pbarrier();                                          // b_k
+            };
+            int ks = ks_begin;
+            for (; ks + NST - 1 < ks_end; ks += NST) {
+                [&]<int... S>(std::integer_sequence<int, S...>) { (stepa(ks + S, std::integral_constant<int, S>()), ...); }
+                (std::make_integer_sequence<int, NST>());
+            }
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                ((ks + S < ks_end ? stepa(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
+            }(std::make_integer_sequence<int, NST - 1>());
+        } else {
+            auto stepb = [&](int ks, auto slot_c) {
+                pbarrier();                                          // a_k
+                reads(slot_c);
+                pbarrier();                                          // b_k
+                mfmas();
+            };
+            int ks = ks_begin;
+            for (; ks + NST - 1 < ks_end; ks += NST) {
+                [&]<int... S>(std::integer_sequence<int, S...>) { (stepb(ks + S, std::integral_constant<int, S>()), ...); }
+                (std::make_integer_sequence<int, NST>());
+            }
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                ((ks + S < ks_end ? stepb(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
+            }(std::make_integer_sequence<int, NST - 1>());
+        }
+    }
     auto step = [&](int ks, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         // my pieces of stage ks have landed when at most the NST-2 younger stages are in flight (near the end fewer were issued:
@@ -491,14 +618,16 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
             }
         }
     };
-    int ks = ks_begin;
-    for (; ks + NST - 1 < ks_end; ks += NST) {                   // (no early exits inside: they would park the accumulators in VGPRs)
-        [&]<int... S>(std::integer_sequence<int, S...>) { (step(ks + S, std::integral_constant<int, S>()), ...); }
-        (std::make_integer_sequence<int, NST>());
+    if constexpr (!PP) {
+        int ks = ks_begin;
+        for (; ks + NST - 1 < ks_end; ks += NST) {               // (no early exits inside: they would park the accumulators in VGPRs)
+            [&]<int... S>(std::integer_sequence<int, S...>) { (step(ks + S, std::integral_constant<int, S>()), ...); }
+            (std::make_integer_sequence<int, NST>());
+        }
+        [&]<int... S>(std::integer_sequence<int, S...>) {        // remainder: up to NST-1 steps
+            ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
+        }(std::make_integer_sequence<int, NST - 1>());
     }
-    [&]<int... S>(std::integer_sequence<int, S...>) {            // remainder: up to NST-1 steps
-        ((ks + S < ks_end ? step(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
-    }(std::make_integer_sequence<int, NST - 1>());
 
     if (wave == 0) cstamp(1);                                     // K loop issued
     if (OMNI_ABL(4) || OMNI_DBG(a, 4)) return;
@@ -1632,6 +1761,12 @@ template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>
 void launch_sh(ShConvArgs a, hipStream_t s)
 {
     const int tiles = ((a.rows + BM - 1) / BM) * (a.Cout / BN);
+    if constexpr (NL > 0 && WM * WN == 8) {
+        if (omni_options().conv_pingpong) {                       // the SIMD's two matrix waves in anti-phase (same bits)
+            hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, NL, true>), dim3(tiles, a.splitk > 1 ? a.splitk : 1), dim3(64 * (WM * WN + NL)), 0, s, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_sh_kernel<BM, BN, WM, WN, NST, NL>), dim3(tiles, a.splitk > 1 ? a.splitk : 1), dim3(64 * (WM * WN + NL)), 0, s, a);
 }
 

@@ -28,6 +28,7 @@ const OptName kOpts[] = {
     {"conv_halo_th", "OMNI_CONV_HALO_TH", &OmniOptions::conv_halo_th, 4},
     {"conv_img", "OMNI_CONV_IMG", &OmniOptions::conv_img, 1},
     {"conv_nodeep", "OMNI_CONV_NODEEP", &OmniOptions::conv_nodeep, 0},
+    {"conv_pingpong", "OMNI_CONV_PINGPONG", &OmniOptions::conv_pingpong, 1},
     {"conv_noxcd", "OMNI_CONV_NOXCD", &OmniOptions::conv_noxcd, 0},
     {"conv_wt_major", "OMNI_CONV_WT_MAJOR", &OmniOptions::conv_wt_major, 1},
     {"conv_stem_pc", "OMNI_CONV_STEM_PC", &OmniOptions::conv_stem_pc, 1},

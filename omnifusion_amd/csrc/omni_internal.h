@@ -30,6 +30,7 @@ struct OmniOptions {
     int conv_halo_th;     // OMNI_CONV_HALO_TH   rows per halo block: 4 (default) | 8
     int conv_img;         // OMNI_CONV_IMG       1 (default): 3x3 stride-1 convolutions of 16-pixel-wide images on the halo kernel (bands of whole rows) when the launch has >= 256 blocks and no split-K | 2: 8-wide too | 0: im2col tiles
     int conv_nodeep;      // OMNI_CONV_NODEEP    1: 3 pipeline stages even for single-round launches
+    int conv_pingpong;    // OMNI_CONV_PINGPONG  1 (default): the 8 + 4-wave tile kernels run the two matrix waves of a SIMD in anti-phase (conv_sh_kernel<.., PP>; same bits) | 0: one barrier per K-step
     int conv_noxcd;       // OMNI_CONV_NOXCD     1: identity block order (no XCD-aware remap)
     int conv_wt_major;    // OMNI_CONV_WT_MAJOR  block order of the tile kernel: 1 (default) weight-stationary per XCD where the weights are the larger operand | 0 never | 2 always
     int conv_stem_pc;     // OMNI_CONV_STEM_PC   1 (default): the stem with producer / consumer waves (8 waves, two image buffers: +2 % one forward at a time, nothing pipelined) | 0: 4 waves

@@ -278,6 +278,72 @@ def test_conv2d_vs_torch(cfg):
 
 
 @pytest.mark.parametrize("cfg", [
+    # M, H, W, C1, C2, Cout, k, stride, pad, act, res, fmt, splitk
+    (144, 8, 8, 256, 0, 256, 3, 1, 1, 1, True, 1, 1),      # layer3 at 8 panoramas: the benched launch (144 blocks of 128 x 128)
+    (131, 8, 8, 256, 0, 256, 3, 1, 1, 1, True, 1, 1),      # ... a ragged last row tile
+    (144, 8, 8, 512, 0, 256, 3, 1, 1, 1, False, 1, 1),     # de_conv0_0
+    (144, 8, 8, 256, 256, 128, 3, 1, 1, 1, False, 1, 2),   # de_conv0_1: two sources, split-K (partial sums to the workspace)
+    (144, 4, 4, 512, 0, 512, 3, 1, 1, 1, True, 1, 4),      # layer4: split-K
+    (144, 16, 16, 128, 0, 256, 3, 2, 1, 1, False, 1, 1),   # layer3.0.c1: stride 2
+    (144, 1, 1, 2048, 0, 512, 1, 1, 0, 0, True, 2, 4),     # fc2: fp32 output, fp32 residual, split-K
+    (144, 16, 16, 64, 0, 64, 1, 1, 0, 2, False, 0, 1),     # 128 x 64 tiles (Cout = 64), GELU, fp32 output
+])
+def test_conv_tile_kernel_pingpong_schedule_gives_the_same_bits(cfg):
+    """Round 6: conv_sh_kernel<.., PP> runs the two matrix waves of every SIMD in anti-phase (two barriers per K-step, one wave group computing while the
+    other reads its fragments; option conv_pingpong, default on).  Same pieces, same fragments, same order on every accumulator: the result must have the
+    BITS of the one-barrier schedule — at the shapes the bench launches (>= 128 blocks: the 8 + 4-wave kernels), split-K included, launch after launch —
+    and agree with a float64 torch reference of the operator."""
+    L, lib = _lib()
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    M, H, W, C1, C2, Cout, k, s, pad, act, use_res, fmt, S = cfg
+    g = torch.Generator().manual_seed(17)
+    x1 = torch.randn(M, H, W, C1, generator=g)
+    x2 = torch.randn(M, H, W, C2, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, k, k, generator=g) / np.sqrt((C1 + C2) * k * k)
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    res = torch.randn(M, Ho, Wo, Cout, generator=g) if use_res else None
+    xin = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=s, padding=pad).permute(0, 2, 3, 1)
+    if use_res:
+        ref = ref + res.double()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    d = lambda t: t.contiguous().to(DEV) if t is not None else None
+    n32 = lambda t: ctypes.c_size_t(t.numel())
+
+    def to_sh(t):
+        if t is None:
+            return None
+        o = torch.empty_like(t)
+        assert lib.omni_sh_from_f32(_p(t), _p(o), n32(t), _stream()) == 0
+        return o
+    X1, X2, B, R = to_sh(d(x1)), to_sh(d(x2)), d(b), d(res)
+    if R is not None and not (fmt & 2):
+        R = to_sh(R)
+    W16 = split_weights_f16x3(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()).to(DEV)
+    ws = torch.empty(max(1, S) * M * Ho * Wo * Cout, device=DEV)
+    outs = {}
+    try:
+        for pp in (0, 1, 0, 1, 1):
+            L.set_option("conv_pingpong", pp)
+            o = torch.full((M, Ho, Wo, Cout), float("nan"), device=DEV)
+            rc = lib.omni_conv2d_sh_f16x3_ws(_p(X1), _p(X2), _p(W16), _p(B), _p(R), _p(o), fmt, M, H, W, C1, C2, Cout, k, k, s, pad, act,
+                                             S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+            assert rc == 0, lib.omni_last_error()
+            if pp in outs:
+                assert torch.equal(o.view(torch.int32), outs[pp].view(torch.int32)), ("not reproducible", pp)
+            outs[pp] = o
+    finally:
+        L.set_option("conv_pingpong", 1)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    o32 = outs[1]
+    if fmt & 1:
+        o32 = torch.empty_like(outs[1])
+        assert lib.omni_sh_to_f32(_p(outs[1]), _p(o32), n32(o32), _stream()) == 0
+    assert (o32.cpu().double() - ref).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("cfg", [
     # M, HW, C1, C2, Cout, res, conv_img
     (72, 16, 128, 0, 128, True, 1),        # layer2 at four panoramas
     (5, 16, 64, 64, 64, False, 1),         # two sources (the decoder's concatenation), a handful of images
@@ -901,7 +967,7 @@ def test_library_kernel_choices_are_result_neutral():
         try:
             Engine.fuse_heads = fuse_heads
             ref = net(rgb, confidence=True).clone()
-            for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1)):
+            for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1), ("conv_pingpong", 0, 1)):
                 try:
                     L.set_option(name, value)
                     out = net(rgb, confidence=True)

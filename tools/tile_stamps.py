@@ -39,3 +39,9 @@ mm = lambda a: float(np.mean(a[4:]))
 M0 = np.array([s[9 + 4 * k] - s[8 + 4 * k] for k in range(27)]); M1 = np.array([s[8 + 4 * (k + 1)] - s[9 + 4 * k] for k in range(27)])
 L = [np.array([s[128 + 4 * k + j + 1] - s[128 + 4 * k + j] for k in range(27)]) for j in range(4)]
 print(f"mean (steps 4..): matrix wave wait + barrier {mm(M0):.0f}, reads + matrix instructions {mm(M1):.0f} (12 matrix instructions = 384 pipe cycles; two matrix waves per SIMD) | loader: wait {mm(L[0]):.0f}, barrier {mm(L[1]):.0f}, issue {mm(L[2]):.0f}, to next step {mm(L[3]):.0f}")
+
+if os.environ.get("OMNI_CONV_PINGPONG", "1") != "0":
+    # the ping-pong schedule (conv_sh_kernel<.., PP>): matrix wave 0 = group A: reads(k) | wait at a_k | its 12 matrix instructions | wait at b_k
+    R = np.array([s[11 + 4 * k] - s[8 + 4 * k] for k in range(27)]); WA = np.array([s[9 + 4 * k] - s[11 + 4 * k] for k in range(27)])
+    MI = np.array([s[10 + 4 * k] - s[9 + 4 * k] for k in range(27)]); WB = np.array([s[8 + 4 * (k + 1)] - s[10 + 4 * k] for k in range(27)])
+    print(f"ping-pong, group A wave 0 (mean over steps 4..): fragment reads + lgkmcnt(0) {mm(R):.0f} | at barrier a_k {mm(WA):.0f} | 12 matrix instructions issued {mm(MI):.0f} | at barrier b_k {mm(WB):.0f} | K step {mm(R) + mm(WA) + mm(MI) + mm(WB):.0f}")

@@ -248,6 +248,57 @@ def png_fed_rate(run, depth, dev, B, src_hw, nfiles, budget_s, pending):
             "decode_pool_alone_panoramas_per_s": pool_rate, "decode_MBps_per_granted_cpu": pool_rate * raw_mb / max(1, min(granted, workers * B)), "batches": nbatch}
 
 
+def dominant_kernel(dev, B):
+    """The dominant kernel of the step alone on the GPU: ONE layer3 convolution (3x3, 256 -> 256 channels, 8 x 8 images, B x 18 patches,
+    residual + ReLU, split-half in and out: conv_sh_kernel<128,128,4,2,3,4,PP>, the form 11 of the 33 encoder convolutions and de_conv0_x run),
+    HIP events around back-to-back launches.  Returns the per-launch figures the roofline check needs."""
+    import ctypes
+    from omnifusion_amd import _lib
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    lib = _lib.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    S_ = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    M, H, W, C, Cout = B * NPATCH, 8, 8, 256, 256
+    K = 9 * C
+
+    def sh(t):
+        o = torch.empty_like(t)
+        assert lib.omni_sh_from_f32(P_(t), P_(o), ctypes.c_size_t(t.numel()), S_()) == 0
+        return o
+    x, res = sh(torch.randn(M, H, W, C, device=dev)), sh(torch.randn(M, H, W, Cout, device=dev))
+    w16 = split_weights_f16x3(torch.randn(Cout, K) / np.sqrt(K)).to(dev)
+    b = torch.randn(Cout, device=dev)
+    out = torch.empty(M, H, W, Cout, device=dev)
+
+    def run():
+        rc = lib.omni_conv2d_sh_f16x3_ws(P_(x), None, P_(w16), P_(b), P_(res), P_(out), 1, M, H, W, C, 0, Cout, 3, 3, 1, 1, 1, 1, None, ctypes.c_size_t(0), S_())
+        assert rc == 0, lib.omni_last_error()
+    t = kernel_us([run], dev, 20)[0]
+    gflop = 2.0 * M * H * W * Cout * K / 1e9
+    blocks = ((M * H * W + 127) // 128) * (Cout // 128)
+    return {"kernel": "conv_sh_kernel<128,128,4,2,3,4,PP> (one layer3 convolution: 3x3, 256->256, 8x8 images, %d patches, residual + ReLU)" % M,
+            "gflop": gflop, "us_alone": t * 1e6, "blocks": blocks, "cus": 256,
+            "achieved_algorithmic_TFLOPs": gflop / t / 1e3, "frac_algorithmic": gflop / t / 1e3 / MFMA_F16_PEAK_TFLOPS,
+            "frac_issued": 3 * gflop / t / 1e3 / MFMA_F16_PEAK_TFLOPS,
+            "frac_issued_on_the_cus_it_occupies": 3 * gflop / t / 1e3 / MFMA_F16_PEAK_TFLOPS * 256 / min(256, blocks),
+            "note": "alone, the launch has %d blocks for 256 CUs (in the timed region other forwards' kernels run on the rest); frac_* against the 2.5-PF dense fp16 peak; "
+                    "three fp16 matrix instructions are ISSUED per algorithmic product block (f16x3)" % blocks}
+
+
+def profile_json(name):
+    """profiles/<name> if it was measured on THIS build (its `build` = source_hash()), else (None, why) — per-kernel counters and time shares the
+    bench line quotes but cannot measure itself (PMC passes, rocprofv3 --stats)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"profiles/{name} not present"
+    with open(path) as fh:
+        d = json.load(fh)
+    from omnifusion_amd.build import source_hash
+    if d.get("build") != source_hash():
+        return None, f"profiles/{name} was measured on build {d.get('build')}, this is {source_hash()}"
+    return d, ""
+
+
 def pmc_traffic(B, name="resample_traffic.json"):
     """HBM bytes from the PMC counters — of the resample pair (one launch each; tools/pmc_traffic.sh -> profiles/resample_traffic.json) or of
     one forward of the network (tools/pmc_net.sh -> profiles/network_traffic.json) — if the file was measured on THIS build, else (None, why)."""
@@ -346,6 +397,12 @@ def main():
                            "fp16_b4": resample_pair(dev, 4, 2048, 4096, 6, 512, torch.float16, reps=8)}
         torch.cuda.empty_cache()
 
+    dominant = dominant_kernel(dev, B) if (rank == 0 and eng.precision == "f16x3") else None
+    if dominant is not None:
+        pm, why = profile_json("conv_pmc.json")                        # tools/pmc_conv.sh: mfma_busy of the same kernel form, hash-matched
+        dominant["mfma_busy_from_profile"] = (pm or {}).get("mfma_busy", {}).get("conv_sh_kernel<128,128,4,2,3,4,PP>")
+        dominant["mfma_busy_note"] = why or (pm or {}).get("note", "")
+    shares, shares_note = profile_json("bench_kernel_shares.json")     # tools/prof_bench.sh: per-kernel-family shares of the timed region's GPU time
     # Bring the GPU out of its idle power state before anything is counted (sclk idles at ~366 MHz and takes tens of
     # milliseconds of load to ramp: a 5-step warm-up measured 1600-2200 panoramas/s on a box that then holds 2650).
     t_heat = time.perf_counter()
@@ -561,6 +618,8 @@ def main():
                      "achieved_issued": (3 * tflops if f16x3 else tflops), "frac_issued": (3 * tflops if f16x3 else tflops) / MFMA_F16_PEAK_TFLOPS,
                      "x_fp32_mfma_peak": tflops / MFMA_F32_PEAK_TFLOPS,
                      "traffic": net_traffic, "traffic_note": net_traffic_note,
+                     "dominant": dominant,
+                     "kernel_time_shares": (shares or {}).get("shares"), "kernel_time_shares_note": shares_note or (shares or {}).get("note", ""),
                      "flops_per_step": NET_GFLOP_PER_PANO * B * 1e9,
                      "achieved_network_section_alone": NET_GFLOP_PER_PANO * B / t_net / 1e3,
                      "note": ("`achieved` / `frac` = ALGORITHMIC flops (71.3 GFLOP per panorama x panoramas / time over the whole timed region, all launches of the "

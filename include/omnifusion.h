@@ -248,6 +248,11 @@ int omni_add_period_sh(void* x, const float* y, size_t total, size_t period, omn
 /* nn.LayerNorm(512) with an SH result, and the attention core on a fused q|k|v projection [B*N, 1536] (q at column 0,
  * k at 512, v at 1024; heads of 128) with an SH result: the f16x3 GEMMs of the transformer consume them directly. */
 int omni_layernorm512_sh(const float* x, const float* g, const float* b, void* y, int rows, float eps, omni_stream_t stream);
+/* x = x + mlp.fc2(h) FOLLOWED BY the next LayerNorm (model/blocks.py:83-88 into the next block's norm1, or into encoder_norm,
+ * model/spherical_model.py:180-187) as a split-K GEMM whose second pass normalises: tok [rows,512] fp32 = x . wt16^T + bias + res (res fp32),
+ * y = LayerNorm(tok) as SH (fmt bit 0) or fp32.  splitk >= 2; ws as for omni_conv2d_sh_f16x3_ws.  The bits of the separate calls, one launch fewer. */
+int omni_gemm_sh_f16x3_ln512_ws(const void* x, const void* wt16, const float* bias, const float* res, float* tok, const float* ln_g, const float* ln_b,
+                                float eps, void* y, int fmt, int rows, int K, int splitk, float* ws, size_t ws_bytes, omni_stream_t stream);
 int omni_attention_qkv_sh(const float* qkv, void* out, int B, int N, omni_stream_t stream);
 /* tokens: reshape(bs,-1,N).transpose(1,2) of the `down` output + pos_emb, model/spherical_model.py:264,181 */
 int omni_token_pack_f32(const float* d, const float* pos, float* tok, int M, int N, int HW, int C, omni_stream_t stream);

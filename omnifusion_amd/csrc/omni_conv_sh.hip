@@ -709,7 +709,7 @@ constexpr int HT_W = 32, HPW = HT_W + 2;
 // matrix instruction at 128 x 128, which is what bounds those layers (tools/convabl.sh: the operand traffic of a layer3 convolution costs
 // as much time as its matrix instructions and overlaps them for a third).  Needs H == W == IW and rows % (TH*32) == 0.
 template <int BN, int TH, bool UP2 = false, int IW = 0>
-__global__ __launch_bounds__(64 * TH) void conv3x3_halo_sh_kernel(ShConvArgs a)
+__global__ __launch_bounds__(64 * TH, (TH == 8 && BN == 32) ? 4 : 1) void conv3x3_halo_sh_kernel(ShConvArgs a)      // (8 rows x 32 channels: 128 registers, two 8-wave blocks per CU)
 {
     static_assert(!UP2 || (TH == 4 && IW == 0), "the cell decomposition of the up-sampling halo is written for 4-row tiles of wide images");
     constexpr int TN = BN / 32, NW = TH, RPP = 8 * NW;
@@ -1577,6 +1577,41 @@ __global__ __launch_bounds__(256) void sh_splitk_reduce_kernel(const float* __re
     splitk_finish(v, o, bias, res, dst, Cout, act, dst_sh, res_f32);
 }
 
+// The same second pass for the transformer's fc2 (model/blocks.py:83-88: x = x + mlp(norm2(x)), then the next block's norm1 / encoder_norm) with the
+// LayerNorm that follows it anyway in the same kernel: tok = sum_s ws[s] + bias + res (fp32, written: it is the next residual) and y = LayerNorm(tok)
+// (SH: the next GEMM's operand, or fp32: encoder_norm).  One wave per row of 512; element for element the operations of sh_splitk_reduce_kernel
+// followed by layernorm512_kernel (omni_net.hip) in their order: the bits of the two launches.
+template <bool SH>
+__global__ __launch_bounds__(256) void sh_splitk_reduce_ln512_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const float* __restrict__ res,
+                                                                     float* __restrict__ tok, const float* __restrict__ g, const float* __restrict__ b,
+                                                                     void* __restrict__ y, int rows, int splitk, size_t slab, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const size_t o = (size_t)row * 512;
+    f4v v0 = *reinterpret_cast<const f4v*>(ws + o + lane * 4), v1 = *reinterpret_cast<const f4v*>(ws + o + 256 + lane * 4);
+    for (int s = 1; s < splitk; ++s) {
+        v0 += *reinterpret_cast<const f4v*>(ws + (size_t)s * slab + o + lane * 4);
+        v1 += *reinterpret_cast<const f4v*>(ws + (size_t)s * slab + o + 256 + lane * 4);
+    }
+    if (bias) { v0 += *reinterpret_cast<const f4v*>(bias + lane * 4); v1 += *reinterpret_cast<const f4v*>(bias + 256 + lane * 4); }
+    if (res) { v0 += *reinterpret_cast<const f4v*>(res + o + lane * 4); v1 += *reinterpret_cast<const f4v*>(res + o + 256 + lane * 4); }
+    *reinterpret_cast<f4v*>(tok + o + lane * 4) = v0; *reinterpret_cast<f4v*>(tok + o + 256 + lane * 4) = v1;
+    float sum = (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    const float mean = sum * (1.0f / 512.0f);
+    v0 -= mean; v1 -= mean;
+    float q = (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + eps);
+    const f4v g0 = *reinterpret_cast<const f4v*>(g + lane * 4), g1 = *reinterpret_cast<const f4v*>(g + 256 + lane * 4);
+    const f4v b0 = *reinterpret_cast<const f4v*>(b + lane * 4), b1 = *reinterpret_cast<const f4v*>(b + 256 + lane * 4);
+    act_store4<SH>(y, o + lane * 4, v0 * rstd * g0 + b0);
+    act_store4<SH>(y, o + 256 + lane * 4, v1 * rstd * g1 + b1);
+}
+
 // fp32 NHWC <-> SH (4 channels per thread)
 __global__ __launch_bounds__(256) void sh_from_f32_kernel(const float* __restrict__ src, void* __restrict__ dst, size_t n4)
 {
@@ -1782,7 +1817,7 @@ void launch_sh(ShConvArgs a, hipStream_t s)
 static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, const float* bias,
                           const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                           int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                          const float* post, size_t post_elems, omni_stream_t stream);
+                          const float* post, size_t post_elems, omni_stream_t stream, bool reduce = true);
 extern "C" int omni_conv2d_sh_f16x3_ws(const void* src1, const void* src2, const void* wt16, const float* bias,
                                        const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                        int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
@@ -1799,12 +1834,30 @@ extern "C" int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, 
     return conv2d_sh_impl(src1, src2, wt16, bias, res, dst, fmt, M, H, W, C1, C2, Cout, KH, KW, stride, pad, act, splitk, ws, ws_bytes,
                           post, post_elems, stream);
 }
+// A split-K GEMM with 512 output columns (the transformer's fc2) whose second pass also applies the LayerNorm that follows: tok [rows,512] fp32 =
+// x . wt16^T + bias + res (res fp32 [rows,512], may alias nothing), y = LayerNorm(tok; ln_g, ln_b, eps) as SH (fmt bit 0) or fp32.  splitk >= 2 (the
+// caller's plan); one launch fewer per transformer layer than omni_conv2d_sh_f16x3_ws + omni_layernorm512_*, the same bits.
+extern "C" int omni_gemm_sh_f16x3_ln512_ws(const void* x, const void* wt16, const float* bias, const float* res, float* tok, const float* ln_g, const float* ln_b,
+                                           float eps, void* y, int fmt, int rows, int K, int splitk, float* ws, size_t ws_bytes, omni_stream_t stream)
+{
+    if (!x || !wt16 || !tok || !ln_g || !ln_b || !y) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_sh_f16x3_ln512: null pointer");
+    if (rows <= 0 || K <= 0 || K % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_sh_f16x3_ln512: bad shape");
+    const int S = std::min(splitk, K / 32);
+    if (S < 2) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_sh_f16x3_ln512: needs a split-K plan (splitk >= 2); an unsplit GEMM writes its result in its own epilogue");
+    const int rc = conv2d_sh_impl(x, nullptr, wt16, bias, res, tok, 2, rows, 1, 1, K, 0, 512, 1, 1, 1, 0, OMNI_ACT_NONE, S, ws, ws_bytes, nullptr, 0, stream, false);
+    if (rc != OMNI_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (fmt & 1) hipLaunchKernelGGL(sh_splitk_reduce_ln512_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)ws, bias, res, tok, ln_g, ln_b, y, rows, S, (size_t)rows * 512, eps);
+    else         hipLaunchKernelGGL(sh_splitk_reduce_ln512_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)ws, bias, res, tok, ln_g, ln_b, y, rows, S, (size_t)rows * 512, eps);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
 extern "C" int omni_conv2d_splitk_plan(long long rows, int Cout, int ksteps);            // omni_conv.hip: the two-launch plan
 
 static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, const float* bias,
                           const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                           int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
-                          const float* post, size_t post_elems, omni_stream_t stream)
+                          const float* post, size_t post_elems, omni_stream_t stream, bool reduce)
 {
     const int dst_sh = fmt & 1;
     if (!src1 || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: null pointer");
@@ -1852,7 +1905,11 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     if (a.splitk <= 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && H == W && (W == 16 || (W == 8 && omni_options().conv_img >= 2)) && rows % 128 == 0 &&
         Cout % 64 == 0 && !(fmt & 4) && omni_options().conv_img > 0 && !omni_options().conv_nohalo) {
         const int grid = (int)(rows / 128) * (Cout / 64);
-        if (W == 16) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 16>), dim3(grid), dim3(256), 0, s, a);
+        if (omni_options().conv_halo_bn == 32) {
+            if (W == 16) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, false, 16>), dim3(2 * grid), dim3(256), 0, s, a);
+            else         hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, false, 8>), dim3(2 * grid), dim3(256), 0, s, a);
+        }
+        else if (W == 16) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 16>), dim3(grid), dim3(256), 0, s, a);
         else         hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, false, 8>), dim3(grid), dim3(256), 0, s, a);
         OMNI_HIP(hipGetLastError());
         return OMNI_OK;
@@ -1861,10 +1918,10 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
         const int th = (H % 8 == 0 && omni_options().conv_halo_th == 8) ? 8 : 4;
         const int grid = M * (H / th) * (W / HT_W);
         if (th == 8) {
-            if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 8>), dim3(grid * (Cout / 64)), dim3(512), 0, s, a);
+            if (Cout % 64 == 0 && omni_options().conv_halo_bn != 32) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 8>), dim3(grid * (Cout / 64)), dim3(512), 0, s, a);
             else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 8>), dim3(grid * (Cout / 32)), dim3(512), 0, s, a);
         } else {
-            if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
+            if (Cout % 64 == 0 && omni_options().conv_halo_bn != 32) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
             else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);
         }
         OMNI_HIP(hipGetLastError());
@@ -1898,7 +1955,7 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !omni_options().conv_nodeep) launch_sh<64, 64, 2, 2, 6>(a, s);
     else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && reduce) {
         const size_t n4 = (size_t)rows * Cout / 4;
         hipLaunchKernelGGL(sh_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, bias, res, dst,
                            n4, Cout, a.splitk, (size_t)rows * Cout, act, a.dst_sh, a.res_f32);
@@ -1934,6 +1991,8 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
         OMNI_HIP(hipGetLastError());
         return OMNI_OK;
     }
+    // (the up-sampling halo is COMPUTED per block — ~700 vector instructions per 2 x 2 cell: blocks of 32 output channels would do it twice — 64 per block here whatever conv_halo_bn says:
+    //  de_conv2_0 51 -> 64 us, de_conv3_0 180 -> 240 us with 32, profiles/r06e_halo_bn.txt)
     if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
     else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, true>), dim3(grid * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, a);
     OMNI_HIP(hipGetLastError());

@@ -26,6 +26,7 @@ const OptName kOpts[] = {
     {"conv_sh_tile", "OMNI_CONV_SH_TILE", &OmniOptions::conv_sh_tile, -1},
     {"conv_nohalo", "OMNI_CONV_NOHALO", &OmniOptions::conv_nohalo, 0},
     {"conv_halo_th", "OMNI_CONV_HALO_TH", &OmniOptions::conv_halo_th, 4},
+    {"conv_halo_bn", "OMNI_CONV_HALO_BN", &OmniOptions::conv_halo_bn, 64},
     {"conv_img", "OMNI_CONV_IMG", &OmniOptions::conv_img, 1},
     {"conv_nodeep", "OMNI_CONV_NODEEP", &OmniOptions::conv_nodeep, 0},
     {"conv_pingpong", "OMNI_CONV_PINGPONG", &OmniOptions::conv_pingpong, 1},
@@ -58,6 +59,7 @@ const OptName kOpts[] = {
     {"e2p_region", "OMNI_E2P_REGION", &OmniOptions::e2p_region, 0},
     {"p2e_band", "OMNI_P2E_BAND", &OmniOptions::p2e_band, 0},
     {"p2e_nbuf", "OMNI_P2E_NBUF", &OmniOptions::p2e_nbuf, 0},
+    {"p2e_lds_kb", "OMNI_P2E_LDS_KB", &OmniOptions::p2e_lds_kb, 0},
     {"p2e_planes", "OMNI_P2E_PLANES", &OmniOptions::p2e_planes, 0},
     {"p2e_walk", "OMNI_P2E_WALK", &OmniOptions::p2e_walk, 1},
     {"p2e_tile8", "OMNI_P2E_TILE8", &OmniOptions::p2e_tile8, 1},

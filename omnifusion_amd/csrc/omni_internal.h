@@ -28,6 +28,7 @@ struct OmniOptions {
     int conv_sh_tile;     // OMNI_CONV_SH_TILE   -1 auto (8-wave 256x128 / 128x128 / 128x64 where >= 128 blocks remain) | 0 64x64 | 1 128x64 | 2 128x128 | 3, 4 the 8-wave forms | 5..7 auto without 256x128 (64 / 128 / 256 blocks) | 8 = auto | 9 = auto without the loader waves
     int conv_nohalo;      // OMNI_CONV_NOHALO    1: never take the halo-reuse 3x3 kernel
     int conv_halo_th;     // OMNI_CONV_HALO_TH   rows per halo block: 4 (default) | 8
+    int conv_halo_bn;     // OMNI_CONV_HALO_BN   output channels per block of the 3x3 halo kernels that COPY their halo (not the up-sampling ones): 64 (default: 74 KiB of LDS, 244 registers -> two blocks per CU) | 32 (50 KiB, 164 registers -> THREE blocks per CU; round 6: each kernel ALONE 11-15 % faster — layer1 46.9 -> 41.8 us, layer2 47.4 -> 40.1, de_conv1_0 44.5 -> 39.3 — but whole forwards equal (plain) or 1 % slower (three in flight: 3992 -> 3955 panoramas/s): twice the halo fetches; profiles/r06e_halo_bn.txt); same bits
     int conv_img;         // OMNI_CONV_IMG       1 (default): 3x3 stride-1 convolutions of 16-pixel-wide images on the halo kernel (bands of whole rows) when the launch has >= 256 blocks and no split-K | 2: 8-wide too | 0: im2col tiles
     int conv_nodeep;      // OMNI_CONV_NODEEP    1: 3 pipeline stages even for single-round launches
     int conv_pingpong;    // OMNI_CONV_PINGPONG  1 (default): the 8 + 4-wave tile kernels run the two matrix waves of a SIMD in anti-phase (conv_sh_kernel<.., PP>; same bits) | 0: one barrier per K-step
@@ -55,6 +56,7 @@ struct OmniOptions {
     int e2p_tile_h;       // OMNI_E2P_TILE_H     sample rows per tile of the equi2pers box kernel: 0 / 8 (default) | 4 | 2: 4 where > 1/8 of the 8-row tiles would gather (measured: wins only at 8 panoramas of 128^2 patches)
     int e2p_slot_kb;      // OMNI_E2P_SLOT_KB    largest tap box staged in LDS (KiB, 1..8; default 6); tiles with a larger box take the gather path
     int p2e_band;         // OMNI_P2E_BAND       tile rows per XCD band of the pers2equi block order (0: max(1, tile rows / 8) — ONE contiguous range of tile rows per XCD)
+    int p2e_lds_kb;       // OMNI_P2E_LDS_KB     0 (default): the ring | n: at least n KiB of LDS per wave of the pers2equi LDS / walk kernels — caps the waves resident per CU at 160 / n (tuning: a launch whose waves are all resident at once marches in step; fewer resident waves are back-filled out of phase)
     int p2e_nbuf;         // OMNI_P2E_NBUF       LDS ring slots (boxes in flight) per wave of the pers2equi LDS kernel: 0 auto | 1 | 2 | 4
     int p2e_planes;       // OMNI_P2E_PLANES     cap of the image planes per wave of the pers2equi LDS kernel: 0 auto (8) | 1 | 2 | 4 | 8
     int p2e_store;        // OMNI_P2E_STORE      ERP stores of the pers2equi LDS kernels: 1 (default) non-temporal | 0 plain

@@ -958,7 +958,7 @@ int launch_p2e_lds_nb(const P2EArgs& a, const omni_geometry* g, int p_first, int
 {
     const auto& tt = g->p2e_tiles[sizeof(T) == 2 ? 1 : 0];
     const int stage_kb = (tt.max_chunks + 63) / 64 * (CONF ? 2 : 1);
-    const size_t lds = (size_t)(stage_kb > P2E_RING_KB ? stage_kb : P2E_RING_KB) * 1024;
+    const size_t lds = std::max((size_t)(stage_kb > P2E_RING_KB ? stage_kb : P2E_RING_KB), (size_t)std::max(0, omni_options().p2e_lds_kb)) * 1024;
     hipLaunchKernelGGL((p2e_lds_kernel<T, PL, CONF, NBMAX>), dim3(tt.nslots, planes / PL), dim3(64), lds, stream, a,
                        (const uint2*)tt.ord, g->p2e_tx, g->p2e_ty, (unsigned)tensor_bytes, p_first);
     OMNI_HIP(hipGetLastError());

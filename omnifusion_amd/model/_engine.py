@@ -270,6 +270,22 @@ class Engine:
         _lib.check(rc, "gemm " + w16key)
         return out
 
+    fuse_fc2_ln = os.environ.get("OMNI_FUSE_FC2_LN", "1") != "0"   # fc2's split-K second pass also applies the LayerNorm that follows (one launch fewer per layer, same bits)
+
+    def _fc2_ln(self, h, w16key, bkey, rows, tok, nxt):
+        """tok + fc2(h) and, where fc2 runs split-K (batches), the LayerNorm `nxt` = (weight key, bias key, eps, SH result?) of the result in the same second
+        pass (omni_gemm_sh_f16x3_ln512_ws).  Returns (new tok, LayerNorm(new tok) or None when the caller has to run it)."""
+        lone = self._bs == 1 and self.latency_plan and self.rows_gemm and rows <= 32
+        S, ws, nb = (1, None, 0) if lone else self._splitk(rows, 512, 2048 // 32, h.device)
+        if lone or S <= 1 or not self.fuse_fc2_ln:
+            return self._gemm_sh(h, w16key, bkey, rows, 2048, 512, res=tok), None
+        wk, bk, eps, out_sh = nxt
+        out, y = torch.empty((rows, 512), dtype=torch.float32, device=h.device), torch.empty((rows, 512), dtype=torch.float32, device=h.device)
+        rc = _lib.load().omni_gemm_sh_f16x3_ln512_ws(_p(h), _p(self.w[w16key]), _p(self.w[bkey]), _p(tok), _p(out), _p(self.w[wk]), _p(self.w[bk]), ctypes.c_float(eps),
+                                                     _p(y), 1 if out_sh else 0, rows, 2048, S, _p(ws), ctypes.c_size_t(nb), self._s)
+        _lib.check(rc, "gemm+ln " + w16key)
+        return out, y
+
     fuse_ln = os.environ.get("OMNI_FUSE_LN", "1") != "0"   # a lone panorama: LayerNorm inside the following rows GEMM (one launch instead of two, same bits)
 
     def _ln_gemm_sh(self, x, lnw, lnb, eps, w16key, bkey, rows, Nout, act=ACT_NONE, out_sh=False):
@@ -364,15 +380,20 @@ class Engine:
         d = self._conv(layer4, "down", M, P32, P32, 512, 32, 1, 1, 0, ACT_NONE, out_f32=True)
         tok = new(M, 512)
         _lib.check(lib.omni_token_pack_f32(_p(d), _p(self.w["pos"]), _p(tok), M, N, P32 * P32, 32, self._s), "token_pack")
+        normed = None                                                # LayerNorm(tok) for the NEXT consumer, when fc2's second pass has already made it
         for i in range(6):
             t = f"t{i}."
             if sh:                                                   # LN / attention emit SH, the GEMMs run f16x3 from it
-                qkv = self._ln_gemm_sh(tok, t + "norm1.weight", t + "norm1.bias", 1e-5, t + "attn.qkv.w16", None, M, 1536)
+                if normed is not None:
+                    qkv = self._gemm_sh(normed, t + "attn.qkv.w16", None, M, 512, 1536)
+                else:
+                    qkv = self._ln_gemm_sh(tok, t + "norm1.weight", t + "norm1.bias", 1e-5, t + "attn.qkv.w16", None, M, 1536)
                 att = new(M, 512)
                 _lib.check(lib.omni_attention_qkv_sh(_p(qkv), _p(att), bs, N, self._s), "attention")
                 tok = self._gemm_sh(att, t + "attn.proj.w16", t + "attn.proj.bias", M, 512, 512, res=tok)
                 h = self._ln_gemm_sh(tok, t + "norm2.weight", t + "norm2.bias", 1e-5, t + "mlp.fc1.w16", t + "mlp.fc1.bias", M, 2048, act=ACT_GELU, out_sh=True)
-                tok = self._gemm_sh(h, t + "mlp.fc2.w16", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
+                nxt = (f"t{i + 1}.norm1.weight", f"t{i + 1}.norm1.bias", 1e-5, True) if i < 5 else ("enc_norm.w", "enc_norm.b", 1e-6, False)
+                tok, normed = self._fc2_ln(h, t + "mlp.fc2.w16", t + "mlp.fc2.bias", M, tok, nxt)
                 continue
             y = self._ln(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)
             q = self._gemm(y, t + "attn.q.weight", None, M, 512, 512)
@@ -383,7 +404,7 @@ class Engine:
             y = self._ln(tok, t + "norm2.weight", t + "norm2.bias", M, 1e-5)
             h = self._gemm(y, t + "mlp.fc1.weight", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU)
             tok = self._gemm(h, t + "mlp.fc2.weight", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
-        tok = self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
+        tok = normed if (sh and normed is not None) else self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
         _lib.check((lib.omni_add_hw_sh if sh else lib.omni_add_hw_f32)(_p(layer4), _p(tok), M, P32 * P32, 512, self._s), "token bias")
         # ---- decoder (:270-302); torch.cat is the two-source form of the conv
         up = self._up(layer4, M, P32, P32, 512, P16, P16)

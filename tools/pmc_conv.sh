@@ -14,7 +14,9 @@ for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLE
   timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o p$i -- python $GRAFT_REPO_ROOT/tools/convbench.py > $out/p$i.log 2>&1
 done
 python - > $GRAFT_REPO_ROOT/gpurun_out/${tag}_conv_pmc.txt <<PY
-import csv, glob, collections
+import csv, glob, collections, json, re, sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from omnifusion_amd.build import source_hash
 agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
 for f in glob.glob("$out/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -25,11 +27,16 @@ for f in glob.glob("$out/p*/*kernel_trace.csv"):
 print("# snapshot $tag — rocprofv3 --kernel-trace --pmc <set> (2 separate passes, tools/pmc_conv.sh) on tools/convbench.py: every convolution shape of the")
 print("# network at 8 panoramas (144 patches), f16x3 SH path; means per dispatch over the shapes a kernel form serves.")
 print("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): share of the launch's SIMD-cycles with a matrix instruction executing")
+busy = {}
 for k, d in sorted(agg.items(), key=lambda kv: -sum(dur[kv[0]])):
     if "conv" not in k: continue
     m = lambda c: sum(d[c]) / len(d[c]) if c in d else float("nan")
+    mt = re.search(r"(\w+<[^>]*>)", k)
+    if mt: busy[mt.group(1).replace(" ", "").replace("true", "PP").replace(",false", "")] = m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)
     print("%s avg_us=%.1f n=%d   mfma_busy=%.1f%%" % (k, sum(dur[k]) / len(dur[k]), len(dur[k]), 100 * m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)))
     for c, v in sorted(d.items()):
         print(f"   {c:40s} mean={sum(v)/len(v):.4g}")
+json.dump({"build": source_hash(), "mfma_busy": busy, "note": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024) per kernel form, each alone on the GPU (tools/pmc_conv.sh on tools/convbench.py, 144 patches); snapshot $tag"},
+          open("$GRAFT_REPO_ROOT/gpurun_out/conv_pmc.json", "w"), indent=1)
 PY
 head -30 $GRAFT_REPO_ROOT/gpurun_out/${tag}_conv_pmc.txt

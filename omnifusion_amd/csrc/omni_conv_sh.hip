@@ -1940,7 +1940,7 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     else if (tile == 1) launch_sh<128, 64, 2, 2>(a, s);
     else if (tile == 3) launch_sh<128, 64, 4, 2>(a, s);            // 8 waves
     else if (tile == 4 && Cout % 128 == 0) launch_sh<128, 128, 4, 2>(a, s);
-    else if (tile == 8 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<256, 128, 4, 2>(a, s);   // each wave a 64x64 tile: 0.67 KB of LDS reads per MFMA instead of 1
+    else if (tile == 8 && Cout % 128 == 0 && ((rows + 255) / 256) * (long long)(Cout / 128) * a.splitk >= std::max(1, omni_options().conv_big_blocks)) launch_sh<256, 128, 4, 2>(a, s);   // each wave a 64x64 tile: 0.67 KB of LDS reads per MFMA instead of 1
     // (128x128 and 128x64 with four LOADER waves beside the eight matrix waves: layer3 51.3 -> 45.8 us, de_conv0_0 90 -> 79, layer4 43.3 -> 41.3, same bits;
     //  tile = 9: without them.  256x128 has no registers to spare for a third wave per SIMD.)
     else if (tile == 8 && Cout % 128 == 0 && ((rows + 127) / 128) * (long long)(Cout / 128) * a.splitk >= 128) launch_sh<128, 128, 4, 2, 3, 4>(a, s);

@@ -5,9 +5,12 @@ tag=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
 # the counters first: bench.py reports them (roofline.traffic) only from files whose build hash is the library's
 tools/pmc_traffic.sh $tag 8 > /dev/null 2>&1
 tools/pmc_net.sh $tag 8 > /dev/null 2>&1
-cp $O/${tag}_resample_traffic.json $R/profiles/resample_traffic.json; cp $O/${tag}_network_traffic.json $R/profiles/network_traffic.json
+tools/pmc_conv.sh $tag > /dev/null 2>&1                      # mfma_busy per kernel form -> conv_pmc.json (roofline.dominant.mfma_busy_from_profile)
+cp $O/${tag}_resample_traffic.json $R/profiles/resample_traffic.json; cp $O/${tag}_network_traffic.json $R/profiles/network_traffic.json; cp $O/conv_pmc.json $R/profiles/conv_pmc.json
+tools/prof_bench.sh $tag > /dev/null 2>&1                    # per-kernel stats of the bench command -> bench_kernel_shares.json (roofline.kernel_time_shares)
+cp $O/bench_kernel_shares.json $R/profiles/bench_kernel_shares.json
 python bench.py > $O/${tag}_bench.log 2>&1; tail -1 $O/${tag}_bench.log > $O/${tag}_bench.json
-tools/prof_bench.sh $tag > /dev/null 2>&1
+python tools/clocks_under_load.py 2>&1 | grep -v amdgpu.ids > $O/${tag}_clocks_under_load.txt
 cd /tmp && export TMPDIR=/tmp
 for b in 8 1; do
   d=$O/prof_${tag}_b$b; rm -rf $d; mkdir -p $d

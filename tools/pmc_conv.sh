@@ -32,7 +32,10 @@ for k, d in sorted(agg.items(), key=lambda kv: -sum(dur[kv[0]])):
     if "conv" not in k: continue
     m = lambda c: sum(d[c]) / len(d[c]) if c in d else float("nan")
     mt = re.search(r"(\w+<[^>]*>)", k)
-    if mt: busy[mt.group(1).replace(" ", "").replace("true", "PP").replace(",false", "")] = m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)
+    if mt:
+        key = mt.group(1).replace(" ", "")
+        if key.startswith("conv_sh_kernel<"): key = key.replace(",true>", ",PP>").replace(",false>", ">")     # (the last template argument: the ping-pong schedule)
+        busy[key] = m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)
     print("%s avg_us=%.1f n=%d   mfma_busy=%.1f%%" % (k, sum(dur[k]) / len(dur[k]), len(dur[k]), 100 * m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)))
     for c, v in sorted(d.items()):
         print(f"   {c:40s} mean={sum(v)/len(v):.4g}")

@@ -1921,7 +1921,10 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
             if (Cout % 64 == 0 && omni_options().conv_halo_bn != 32) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 8>), dim3(grid * (Cout / 64)), dim3(512), 0, s, a);
             else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 8>), dim3(grid * (Cout / 32)), dim3(512), 0, s, a);
         } else {
-            if (Cout % 64 == 0 && omni_options().conv_halo_bn != 32) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
+            // (fmt bit 2, ONE panorama: the launch is a fraction of a block per CU and costs the length of a block's life — 32-channel blocks are twice as many and
+            //  half as long; option conv_halo_bn_lat)
+            const bool bn32 = omni_options().conv_halo_bn == 32 || ((fmt & 4) && omni_options().conv_halo_bn_lat == 32);
+            if (Cout % 64 == 0 && !bn32) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4>), dim3(grid * (Cout / 64)), dim3(256), 0, s, a);
             else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4>), dim3(grid * (Cout / 32)), dim3(256), 0, s, a);
         }
         OMNI_HIP(hipGetLastError());
@@ -1952,7 +1955,12 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     else if (tile >= 5 && tile <= 7 && ((rows + 127) / 128) * (long long)(Cout / 64) * a.splitk >= (32ll << (tile - 4))) launch_sh<128, 64, 4, 2>(a, s);
     // one round of at most one block per CU (the transformer GEMMs; every deep layer at batch 1): the K loop is pure latency,
     // keep 5 stages in flight instead of 2 (96 KiB of LDS, which a single resident block can afford)
-    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !omni_options().conv_nodeep) launch_sh<64, 64, 2, 2, 6>(a, s);
+    else if (((rows + 63) / 64) * (long long)(Cout / 64) * a.splitk <= 256 && ksteps >= 8 && !omni_options().conv_nodeep) {
+        // (conv_deep_loaders = 1: four loader waves beside the four matrix waves — at one block per CU a K-step is the four DMA pieces a matrix wave issues,
+        //  ~400 cycles for its 192 of matrix work)
+        if (omni_options().conv_deep_loaders) launch_sh<64, 64, 2, 2, 6, 4>(a, s);
+        else launch_sh<64, 64, 2, 2, 6>(a, s);
+    }
     else launch_sh<64, 64, 2, 2>(a, s);
     OMNI_HIP(hipGetLastError());
     if (a.splitk > 1 && reduce) {
@@ -1993,7 +2001,7 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
     }
     // (the up-sampling halo is COMPUTED per block — ~700 vector instructions per 2 x 2 cell: blocks of 32 output channels would do it twice — 64 per block here whatever conv_halo_bn says:
     //  de_conv2_0 51 -> 64 us, de_conv3_0 180 -> 240 us with 32, profiles/r06e_halo_bn.txt)
-    if (Cout % 64 == 0) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
+    if (Cout % 64 == 0 && !((fmt & 4) && omni_options().conv_halo_up2_bn_lat == 32)) hipLaunchKernelGGL((conv3x3_halo_sh_kernel<64, 4, true>), dim3(grid * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, a);
     else                hipLaunchKernelGGL((conv3x3_halo_sh_kernel<32, 4, true>), dim3(grid * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, a);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;

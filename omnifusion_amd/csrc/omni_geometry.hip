@@ -27,6 +27,9 @@ const OptName kOpts[] = {
     {"conv_nohalo", "OMNI_CONV_NOHALO", &OmniOptions::conv_nohalo, 0},
     {"conv_halo_th", "OMNI_CONV_HALO_TH", &OmniOptions::conv_halo_th, 4},
     {"conv_big_blocks", "OMNI_CONV_BIG_BLOCKS", &OmniOptions::conv_big_blocks, 128},
+    {"conv_halo_bn_lat", "OMNI_CONV_HALO_BN_LAT", &OmniOptions::conv_halo_bn_lat, 32},
+    {"conv_deep_loaders", "OMNI_CONV_DEEP_LOADERS", &OmniOptions::conv_deep_loaders, 1},
+    {"conv_halo_up2_bn_lat", "OMNI_CONV_HALO_UP2_BN_LAT", &OmniOptions::conv_halo_up2_bn_lat, 64},
     {"conv_halo_bn", "OMNI_CONV_HALO_BN", &OmniOptions::conv_halo_bn, 64},
     {"conv_img", "OMNI_CONV_IMG", &OmniOptions::conv_img, 1},
     {"conv_nodeep", "OMNI_CONV_NODEEP", &OmniOptions::conv_nodeep, 0},

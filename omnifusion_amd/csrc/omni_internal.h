@@ -28,6 +28,9 @@ struct OmniOptions {
     int conv_sh_tile;     // OMNI_CONV_SH_TILE   -1 auto (8-wave 256x128 / 128x128 / 128x64 where >= 128 blocks remain) | 0 64x64 | 1 128x64 | 2 128x128 | 3, 4 the 8-wave forms | 5..7 auto without 256x128 (64 / 128 / 256 blocks) | 8 = auto | 9 = auto without the loader waves
     int conv_nohalo;      // OMNI_CONV_NOHALO    1: never take the halo-reuse 3x3 kernel
     int conv_halo_th;     // OMNI_CONV_HALO_TH   rows per halo block: 4 (default) | 8
+    int conv_halo_bn_lat; // OMNI_CONV_HALO_BN_LAT  the same choice for the LATENCY form (fmt bit 2: one panorama per forward, a fraction of a block per CU): 32 (default: 0.956 -> 0.942 ms per forward) | 64
+    int conv_halo_up2_bn_lat; // OMNI_CONV_HALO_UP2_BN_LAT  ... and for the up-sampling halo kernels in the latency form: 64 | 32 (twice the halo arithmetic, half the block life)
+    int conv_deep_loaders; // OMNI_CONV_DEEP_LOADERS  1 (default, round 6: one panorama 0.966 -> 0.930 ms per forward, batches unchanged): the 64 x 64 six-stage tile kernel of single-round launches (one panorama; the transformer GEMMs) with four loader waves | 0
     int conv_big_blocks;  // OMNI_CONV_BIG_BLOCKS  least number of 256 x 128 blocks a launch must have to take that tile (default 128; the chip is power-bound in the timed region — profiles/r06h_clocks_under_load.txt — so fewer LDS / L2 bytes per matrix instruction may beat filling more CUs)
     int conv_halo_bn;     // OMNI_CONV_HALO_BN   output channels per block of the 3x3 halo kernels that COPY their halo (not the up-sampling ones): 64 (default: 74 KiB of LDS, 244 registers -> two blocks per CU) | 32 (50 KiB, 164 registers -> THREE blocks per CU; round 6: each kernel ALONE 11-15 % faster — layer1 46.9 -> 41.8 us, layer2 47.4 -> 40.1, de_conv1_0 44.5 -> 39.3 — but whole forwards equal (plain) or 1 % slower (three in flight: 3992 -> 3955 panoramas/s): twice the halo fetches; profiles/r06e_halo_bn.txt); same bits
     int conv_img;         // OMNI_CONV_IMG       1 (default): 3x3 stride-1 convolutions of 16-pixel-wide images on the halo kernel (bands of whole rows) when the launch has >= 256 blocks and no split-K | 2: 8-wide too | 0: im2col tiles

@@ -1001,12 +1001,13 @@ def test_library_kernel_choices_are_result_neutral():
     for fuse_heads in (True, False):                                          # (conv_up2_persist selects de_conv4_0's kernel only when the heads are a kernel of their own)
         try:
             Engine.fuse_heads = fuse_heads
-            ref = net(rgb, confidence=True).clone()
-            for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1), ("conv_pingpong", 0, 1), ("conv_halo_bn", 32, 64)):
+            ref, ref1 = net(rgb, confidence=True).clone(), net(rgb[:1].contiguous(), confidence=True).clone()    # (a lone panorama runs the latency forms)
+            for name, value, default in (("conv_stem_pc", 0, 1), ("conv_epi_lds", 0, 1), ("conv_sh_tile", 9, -1), ("conv_up2_persist", 0, 1), ("conv_pingpong", 0, 1), ("conv_halo_bn", 32, 64), ("conv_deep_loaders", 0, 1), ("conv_halo_bn_lat", 64, 32)):
                 try:
                     L.set_option(name, value)
                     out = net(rgb, confidence=True)
                     assert torch.equal(out, ref), (name, fuse_heads)
+                    assert torch.equal(net(rgb[:1].contiguous(), confidence=True), ref1), (name, fuse_heads, "one panorama")
                 finally:
                     L.set_option(name, default)
         finally:

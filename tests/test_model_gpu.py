@@ -441,6 +441,47 @@ def test_sh_elementwise_ops_match_f32():
     assert (from_sh(to_sh(t)) - t).abs().max().item() < 2.0 ** -25
 
 
+@pytest.mark.parametrize("rows,S,out_sh", [(144, 4, True), (144, 3, False), (50, 2, True), (18, 8, False)])
+def test_fc2_second_pass_with_layernorm_gives_the_bits_of_the_two_calls(rows, S, out_sh):
+    """omni_gemm_sh_f16x3_ln512_ws (round 6): x . W^T + bias + residual as a split-K GEMM whose second pass also applies the LayerNorm that follows
+    (model/blocks.py:83-88 into the next norm1 / encoder_norm) — the token matrix AND its LayerNorm must have the bits of omni_conv2d_sh_f16x3_ws
+    followed by omni_layernorm512_sh / _f32, and agree with a float64 torch restatement."""
+    L, lib = _lib()
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    g = torch.Generator().manual_seed(40 + rows + S)
+    K = 2048
+    x, w = torch.randn(rows, K, generator=g), torch.randn(512, K, generator=g) / np.sqrt(K)
+    b, res = torch.randn(512, generator=g), torch.randn(rows, 512, generator=g)
+    lg, lb = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    eps = 1e-5 if out_sh else 1e-6
+    X = x.to(DEV); XS = torch.empty_like(X)
+    assert lib.omni_sh_from_f32(_p(X), _p(XS), ctypes.c_size_t(X.numel()), _stream()) == 0
+    W16, B, R, LG, LB = split_weights_f16x3(w).to(DEV), b.to(DEV), res.to(DEV), lg.to(DEV), lb.to(DEV)
+    ws = torch.empty(S * rows * 512, device=DEV)
+    tok2, y2 = torch.empty((rows, 512), device=DEV), torch.empty((rows, 512), device=DEV)
+    assert lib.omni_conv2d_sh_f16x3_ws(_p(XS), None, _p(W16), _p(B), _p(R), _p(tok2), 2, rows, 1, 1, K, 0, 512, 1, 1, 1, 0, 0, S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()) == 0
+    ln = lib.omni_layernorm512_sh if out_sh else lib.omni_layernorm512_f32
+    assert ln(_p(tok2), _p(LG), _p(LB), _p(y2), rows, ctypes.c_float(eps), _stream()) == 0
+    for rep in range(2):
+        tok1, y1 = torch.full((rows, 512), float("nan"), device=DEV), torch.full((rows, 512), float("nan"), device=DEV)
+        ws.fill_(float("nan"))
+        rc = lib.omni_gemm_sh_f16x3_ln512_ws(_p(XS), _p(W16), _p(B), _p(R), _p(tok1), _p(LG), _p(LB), ctypes.c_float(eps), _p(y1), 1 if out_sh else 0,
+                                             rows, K, S, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+        assert rc == 0, lib.omni_last_error()
+        assert torch.equal(tok1, tok2) and torch.equal(y1.view(torch.int32), y2.view(torch.int32)), rep
+    t64 = x.double() @ w.double().T + b.double() + res.double()
+    assert (tok1.cpu().double() - t64).abs().max().item() < 3e-5
+    y64 = F.layer_norm(t64, (512,), lg.double(), lb.double(), eps)
+    yf = y1
+    if out_sh:
+        yf = torch.empty_like(y1)
+        assert lib.omni_sh_to_f32(_p(y1), _p(yf), ctypes.c_size_t(yf.numel()), _stream()) == 0
+    assert (yf.cpu().double() - y64).abs().max().item() < 1e-4
+    # an unsplit call is refused (an unsplit GEMM finishes in its own epilogue), as is a workspace that cannot hold the partial sums
+    assert lib.omni_gemm_sh_f16x3_ln512_ws(_p(XS), _p(W16), _p(B), _p(R), _p(tok1), _p(LG), _p(LB), ctypes.c_float(eps), _p(y1), 0, rows, K, 1, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()) != 0
+    assert lib.omni_gemm_sh_f16x3_ln512_ws(_p(XS), _p(W16), _p(B), _p(R), _p(tok1), _p(LG), _p(LB), ctypes.c_float(eps), _p(y1), 0, rows, K, S, _p(ws), ctypes.c_size_t(16), _stream()) != 0
+
+
 def test_small_ops_vs_torch():
     L, lib = _lib()
     g = torch.Generator().manual_seed(2)

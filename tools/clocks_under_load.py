@@ -20,11 +20,18 @@ _HW = None
 
 
 def _hwmon():
-    """the amdgpu hwmon directory of GPU 0 (power1_average / power1_input in microwatts, freq1_input = sclk in Hz), or None"""
+    """the amdgpu hwmon directory of THE GPU torch runs on (matched by PCI address: a box may show the hwmon files of the host's other GPUs too —
+    card0 is not necessarily this one), or None.  power1_average / power1_input in microwatts, freq1_input = sclk in Hz."""
     global _HW
     if _HW is None:
-        c = [d for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if os.path.exists(d + "/freq1_input")]
-        _HW = c[0] if c else ""
+        _HW = ""
+        try:
+            p = torch.cuda.get_device_properties(0)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            c = [d for d in sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")) if os.path.exists(d + "/freq1_input")]
+            _HW = c[0] if c else ""
+        except Exception:
+            pass
     return _HW or None
 
 

@@ -248,6 +248,16 @@ int omni_add_period_sh(void* x, const float* y, size_t total, size_t period, omn
 /* nn.LayerNorm(512) with an SH result, and the attention core on a fused q|k|v projection [B*N, 1536] (q at column 0,
  * k at 512, v at 1024; heads of 128) with an SH result: the f16x3 GEMMs of the transformer consume them directly. */
 int omni_layernorm512_sh(const float* x, const float* g, const float* b, void* y, int rows, float eps, omni_stream_t stream);
+/* A lone panorama's fc2 (K = 2048, <= 32 rows) in K slices: N / 32 x slices blocks stream the weights instead of N / 32; each slice's RAW partial sums go to
+ * parts[slice][rows][N] (fp32).  The consumer adds them up: omni_gemm_rows_ln_parts_sh_f16x3 (x = sum parts + pbias + pres -> xout, then LayerNorm + the rows
+ * GEMM of omni_gemm_rows_ln_sh_f16x3: the next Transformer_Block's norm1 + qkv, model/blocks.py:83-88) or omni_splitk_reduce_ln512 (encoder_norm,
+ * model/spherical_model.py:186).  slices in {1, 2, 4}. */
+int omni_gemm_rows_slices_sh_f16x3(const void* x, const void* wt16r, float* parts, int rows, int K, int N, int slices, omni_stream_t stream);
+int omni_gemm_rows_ln_parts_sh_f16x3(const float* parts, int nparts, const float* pbias, const float* pres, float* xout,
+                                     const float* ln_weight, const float* ln_bias, float eps, const void* wt16r, const float* bias,
+                                     void* dst, int fmt, int rows, int N, int act, omni_stream_t stream);
+int omni_splitk_reduce_ln512(const float* parts, int nparts, const float* bias, const float* res, float* tok, const float* ln_weight, const float* ln_bias,
+                             float eps, void* y, int fmt, int rows, omni_stream_t stream);
 /* x = x + mlp.fc2(h) FOLLOWED BY the next LayerNorm (model/blocks.py:83-88 into the next block's norm1, or into encoder_norm,
  * model/spherical_model.py:180-187) as a split-K GEMM whose second pass normalises: tok [rows,512] fp32 = x . wt16^T + bias + res (res fp32),
  * y = LayerNorm(tok) as SH (fmt bit 0) or fp32.  splitk >= 2; ws as for omni_conv2d_sh_f16x3_ws.  The bits of the separate calls, one launch fewer. */

@@ -1640,6 +1640,9 @@ __global__ __launch_bounds__(256) void sh_to_f32_kernel(const void* __restrict__
 struct RowsGemmArgs {
     const void* x; const void* wt; const float* bias; const float* res; void* dst;
     int rows, K, N, act, dst_sh;
+    // K slices (round 6): gemm_rows_sh_kernel with blockIdx.y = slice s writes its RAW partial sums to parts[s][rows][N] (no bias / residual / activation);
+    // gemm_rows_ln_sh_kernel with nparts > 0 takes its input as x = sum_s parts[s] + pbias + pres (and block 0 writes it to xout: the next residual)
+    float* parts; int nparts; const float* pbias; const float* pres; float* xout;
 };
 
 // dst (fragment order, see gemm_rows_sh_kernel) <- src [N][K/32][hi32|lo32]; one 16-byte piece per thread
@@ -1660,7 +1663,7 @@ __global__ __launch_bounds__(512) void gemm_rows_sh_kernel(RowsGemmArgs a)
     constexpr int NWV = 8, DEPTH = KPW < 4 ? KPW : 4, PITCH = 36;
     __shared__ float red[NWV][32][PITCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
-    const int col0 = blockIdx.x * 32, ksteps = a.K >> 5, ks0 = wave * KPW;
+    const int col0 = blockIdx.x * 32, ksteps = a.K >> 5, ks0 = (blockIdx.y * NWV + wave) * KPW;       // (blockIdx.y: the K slice of a sliced launch)
     // weights in FRAGMENT ORDER (omni_gemm_rows_pack): [column tile][K-step][hi kc0, hi kc1, lo kc0, lo kc1][lane] x 16 B — a wave's load is
     // one contiguous KiB (8 cache lines) instead of 32 B out of each of 32 lines 8 KiB apart, which made the address unit the bound
     const unsigned char* wp = (const unsigned char*)a.wt + ((size_t)blockIdx.x * ksteps + ks0) * 4096 + lane * 16;
@@ -1704,6 +1707,7 @@ __global__ __launch_bounds__(512) void gemm_rows_sh_kernel(RowsGemmArgs a)
 #pragma unroll
     for (int w = 1; w < NWV; ++w) v += *reinterpret_cast<const f4v*>(&red[w][tok][c4]);
     const size_t o = (size_t)tok * a.N + col0 + c4;
+    if (a.parts) { *reinterpret_cast<f4v*>(a.parts + (size_t)blockIdx.y * a.rows * a.N + o) = v; return; }     // a K slice: raw partial sums
     if (a.bias) v += *reinterpret_cast<const f4v*>(a.bias + col0 + c4);
     if (a.res) v += *reinterpret_cast<const f4v*>(a.res + o);
     if (a.act == OMNI_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -1737,8 +1741,23 @@ __global__ __launch_bounds__(512) void gemm_rows_ln_sh_kernel(RowsGemmArgs a, co
         }
     // ---- LayerNorm, one wave per row (rows wave, wave + 8, ...): layernorm512_kernel<true>, writing to LDS
     for (int row = wave; row < a.rows; row += NWV) {
-        const float* p = (const float*)a.x + (size_t)row * 512;
-        f4v v0 = *reinterpret_cast<const f4v*>(p + lane * 4), v1 = *reinterpret_cast<const f4v*>(p + 256 + lane * 4);
+        f4v v0, v1;
+        if (a.nparts > 0) {
+            // the input is the previous GEMM's K slices: x = (slice 0 + slice 1 + ...) + bias + residual, in that order (sh_splitk_reduce_ln512_kernel's);
+            // every block forms it for itself, block 0 also stores it (the next residual)
+            const size_t o = (size_t)row * 512, slab = (size_t)a.rows * 512;
+            v0 = *reinterpret_cast<const f4v*>(a.parts + o + lane * 4); v1 = *reinterpret_cast<const f4v*>(a.parts + o + 256 + lane * 4);
+            for (int sl = 1; sl < a.nparts; ++sl) {
+                v0 += *reinterpret_cast<const f4v*>(a.parts + sl * slab + o + lane * 4);
+                v1 += *reinterpret_cast<const f4v*>(a.parts + sl * slab + o + 256 + lane * 4);
+            }
+            if (a.pbias) { v0 += *reinterpret_cast<const f4v*>(a.pbias + lane * 4); v1 += *reinterpret_cast<const f4v*>(a.pbias + 256 + lane * 4); }
+            if (a.pres) { v0 += *reinterpret_cast<const f4v*>(a.pres + o + lane * 4); v1 += *reinterpret_cast<const f4v*>(a.pres + o + 256 + lane * 4); }
+            if (blockIdx.x == 0 && a.xout) { *reinterpret_cast<f4v*>(a.xout + o + lane * 4) = v0; *reinterpret_cast<f4v*>(a.xout + o + 256 + lane * 4) = v1; }
+        } else {
+            const float* p = (const float*)a.x + (size_t)row * 512;
+            v0 = *reinterpret_cast<const f4v*>(p + lane * 4); v1 = *reinterpret_cast<const f4v*>(p + 256 + lane * 4);
+        }
         float s = (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -2085,6 +2104,7 @@ extern "C" int omni_gemm_rows_sh_f16x3(const void* x, const void* wt16, const fl
     if (K != 512 && K != 2048) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_gemm_rows_sh: K must be 512 or 2048");
     RowsGemmArgs a;
     a.x = x; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.rows = rows; a.K = K; a.N = N; a.act = act; a.dst_sh = fmt & 1;
+    a.parts = nullptr; a.nparts = 0; a.pbias = nullptr; a.pres = nullptr; a.xout = nullptr;
     if (K == 512) hipLaunchKernelGGL(gemm_rows_sh_kernel<2>, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a);
     else          hipLaunchKernelGGL(gemm_rows_sh_kernel<8>, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a);
     OMNI_HIP(hipGetLastError());
@@ -2100,7 +2120,57 @@ extern "C" int omni_gemm_rows_ln_sh_f16x3(const float* x, const float* lg, const
     if (rows <= 0 || rows > 32 || N <= 0 || N % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_ln_sh: 1..32 rows, N a multiple of 32");
     RowsGemmArgs a;
     a.x = x; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.rows = rows; a.K = 512; a.N = N; a.act = act; a.dst_sh = fmt & 1;
+    a.parts = nullptr; a.nparts = 0; a.pbias = nullptr; a.pres = nullptr; a.xout = nullptr;
     hipLaunchKernelGGL(gemm_rows_ln_sh_kernel, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a, lg, lb, eps);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// The K = 2048 rows GEMM (a lone panorama's fc2) as `slices` K slices over blockIdx.y: N / 32 x slices blocks instead of N / 32 — 16 blocks stream
+// the 4 MB of fc2's weights in ~12 us, 64 in a third of that — each writing its RAW partial sums to parts[slice][rows][N] (fp32, no bias / residual).
+// The consumer sums them: omni_gemm_rows_ln_parts_sh_f16x3 (the next block's norm1 + qkv) or omni_splitk_reduce_ln512 (encoder_norm).
+// slices in {1, 2, 4} (K / 32 / slices / 8 K-steps per wave).
+extern "C" int omni_gemm_rows_slices_sh_f16x3(const void* x, const void* wt16, float* parts, int rows, int K, int N, int slices, omni_stream_t stream)
+{
+    if (!x || !wt16 || !parts) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_slices_sh: null pointer");
+    if (rows <= 0 || rows > 32 || N <= 0 || N % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_slices_sh: 1..32 rows, N a multiple of 32");
+    if (K != 2048 || (slices != 1 && slices != 2 && slices != 4)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_gemm_rows_slices_sh: K = 2048 in 1, 2 or 4 slices");
+    RowsGemmArgs a;
+    a.x = x; a.wt = wt16; a.bias = nullptr; a.res = nullptr; a.dst = nullptr; a.rows = rows; a.K = K; a.N = N; a.act = OMNI_ACT_NONE; a.dst_sh = 0;
+    a.parts = parts; a.nparts = slices; a.pbias = nullptr; a.pres = nullptr; a.xout = nullptr;
+    const dim3 grid(N / 32, slices);
+    if (slices == 4)      hipLaunchKernelGGL(gemm_rows_sh_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, a);
+    else if (slices == 2) hipLaunchKernelGGL(gemm_rows_sh_kernel<4>, grid, dim3(512), 0, (hipStream_t)stream, a);
+    else                  hipLaunchKernelGGL(gemm_rows_sh_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, a);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// omni_gemm_rows_ln_sh_f16x3 whose input is the previous GEMM's K slices: x = sum_s parts[s] + pbias + pres (fp32 [rows,512]; pbias / pres may be null),
+// written to xout (the next residual) by one block; then LayerNorm + the rows GEMM as before.
+extern "C" int omni_gemm_rows_ln_parts_sh_f16x3(const float* parts, int nparts, const float* pbias, const float* pres, float* xout,
+                                                const float* lg, const float* lb, float eps, const void* wt16, const float* bias,
+                                                void* dst, int fmt, int rows, int N, int act, omni_stream_t stream)
+{
+    if (!parts || nparts < 1 || nparts > 8 || !xout || !lg || !lb || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_ln_parts_sh: null pointer or 1..8 slices");
+    if (rows <= 0 || rows > 32 || N <= 0 || N % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_gemm_rows_ln_parts_sh: 1..32 rows, N a multiple of 32");
+    RowsGemmArgs a;
+    a.x = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = dst; a.rows = rows; a.K = 512; a.N = N; a.act = act; a.dst_sh = fmt & 1;
+    a.parts = const_cast<float*>(parts); a.nparts = nparts; a.pbias = pbias; a.pres = pres; a.xout = xout;
+    hipLaunchKernelGGL(gemm_rows_ln_sh_kernel, dim3(N / 32), dim3(512), 0, (hipStream_t)stream, a, lg, lb, eps);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// tok [rows,512] = sum_s parts[s] + bias + res, y = LayerNorm(tok) as SH (fmt bit 0) or fp32: the second pass of a split-K / K-sliced GEMM with 512
+// columns on its own (sh_splitk_reduce_ln512_kernel; omni_gemm_sh_f16x3_ln512_ws runs it behind its GEMM).
+extern "C" int omni_splitk_reduce_ln512(const float* parts, int nparts, const float* bias, const float* res, float* tok, const float* lg, const float* lb,
+                                        float eps, void* y, int fmt, int rows, omni_stream_t stream)
+{
+    if (!parts || nparts < 1 || !tok || !lg || !lb || !y || rows <= 0) OMNI_FAIL(OMNI_ERR_INVALID, "omni_splitk_reduce_ln512: null pointer or empty input");
+    hipStream_t s = (hipStream_t)stream;
+    if (fmt & 1) hipLaunchKernelGGL(sh_splitk_reduce_ln512_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, parts, bias, res, tok, lg, lb, y, rows, nparts, (size_t)rows * 512, eps);
+    else         hipLaunchKernelGGL(sh_splitk_reduce_ln512_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, parts, bias, res, tok, lg, lb, y, rows, nparts, (size_t)rows * 512, eps);
     OMNI_HIP(hipGetLastError());
     return OMNI_OK;
 }

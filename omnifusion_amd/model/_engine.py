@@ -272,19 +272,37 @@ class Engine:
 
     fuse_fc2_ln = os.environ.get("OMNI_FUSE_FC2_LN", "1") != "0"   # fc2's split-K second pass also applies the LayerNorm that follows (one launch fewer per layer, same bits)
 
+    fc2_slices = int(os.environ.get("OMNI_FC2_SLICES", "4"))       # a lone panorama: fc2 in this many K slices (1: off) — 16 blocks stream its 4 MB of weights otherwise
+
     def _fc2_ln(self, h, w16key, bkey, rows, tok, nxt):
-        """tok + fc2(h) and, where fc2 runs split-K (batches), the LayerNorm `nxt` = (weight key, bias key, eps, SH result?) of the result in the same second
-        pass (omni_gemm_sh_f16x3_ln512_ws).  Returns (new tok, LayerNorm(new tok) or None when the caller has to run it)."""
+        """tok + fc2(h).  Batches: where fc2 runs split-K, the LayerNorm `nxt` = (weight key, bias key, eps, SH result?) of the result in the same second
+        pass (omni_gemm_sh_f16x3_ln512_ws).  A lone panorama: fc2 as K slices whose sum the NEXT kernel forms (omni_gemm_rows_slices_sh_f16x3).
+        Returns (new tok or None, LayerNorm(new tok) or None, pending K slices or None)."""
         lone = self._bs == 1 and self.latency_plan and self.rows_gemm and rows <= 32
+        if lone and self.fc2_slices > 1 and self.fuse_ln:
+            S = self.fc2_slices
+            parts = torch.empty((S, rows, 512), dtype=torch.float32, device=h.device)
+            _lib.check(_lib.load().omni_gemm_rows_slices_sh_f16x3(_p(h), _p(self._rows_weights(w16key, 512, 2048)), _p(parts), rows, 2048, 512, S, self._s), "gemm slices " + w16key)
+            return None, None, (parts, S, bkey, tok)
         S, ws, nb = (1, None, 0) if lone else self._splitk(rows, 512, 2048 // 32, h.device)
         if lone or S <= 1 or not self.fuse_fc2_ln:
-            return self._gemm_sh(h, w16key, bkey, rows, 2048, 512, res=tok), None
+            return self._gemm_sh(h, w16key, bkey, rows, 2048, 512, res=tok), None, None
         wk, bk, eps, out_sh = nxt
         out, y = torch.empty((rows, 512), dtype=torch.float32, device=h.device), torch.empty((rows, 512), dtype=torch.float32, device=h.device)
         rc = _lib.load().omni_gemm_sh_f16x3_ln512_ws(_p(h), _p(self.w[w16key]), _p(self.w[bkey]), _p(tok), _p(out), _p(self.w[wk]), _p(self.w[bk]), ctypes.c_float(eps),
                                                      _p(y), 1 if out_sh else 0, rows, 2048, S, _p(ws), ctypes.c_size_t(nb), self._s)
         _lib.check(rc, "gemm+ln " + w16key)
-        return out, y
+        return out, y, None
+
+    def _ln_gemm_parts(self, pending, lnw, lnb, eps, w16key, rows, Nout):
+        """the next block's norm1 + qkv on a token matrix that still is fc2's K slices: (tok, qkv)"""
+        parts, S, bkey, res_tok = pending
+        tok = torch.empty((rows, 512), dtype=torch.float32, device=parts.device)
+        out = torch.empty((rows, Nout), dtype=torch.float32, device=parts.device)
+        rc = _lib.load().omni_gemm_rows_ln_parts_sh_f16x3(_p(parts), S, _p(self.w[bkey]), _p(res_tok), _p(tok), _p(self.w[lnw]), _p(self.w[lnb]), ctypes.c_float(eps),
+                                                          _p(self._rows_weights(w16key, Nout, 512)), None, _p(out), 0, rows, Nout, ACT_NONE, self._s)
+        _lib.check(rc, "ln+gemm (slices) " + w16key)
+        return tok, out
 
     fuse_ln = os.environ.get("OMNI_FUSE_LN", "1") != "0"   # a lone panorama: LayerNorm inside the following rows GEMM (one launch instead of two, same bits)
 
@@ -381,10 +399,14 @@ class Engine:
         tok = new(M, 512)
         _lib.check(lib.omni_token_pack_f32(_p(d), _p(self.w["pos"]), _p(tok), M, N, P32 * P32, 32, self._s), "token_pack")
         normed = None                                                # LayerNorm(tok) for the NEXT consumer, when fc2's second pass has already made it
+        pending = None                                               # a lone panorama: fc2's K slices (parts, slices, bias key, residual) — the next consumer adds them up
         for i in range(6):
             t = f"t{i}."
             if sh:                                                   # LN / attention emit SH, the GEMMs run f16x3 from it
-                if normed is not None:
+                if pending is not None:
+                    tok, qkv = self._ln_gemm_parts(pending, t + "norm1.weight", t + "norm1.bias", 1e-5, t + "attn.qkv.w16", M, 1536)
+                    pending = None
+                elif normed is not None:
                     qkv = self._gemm_sh(normed, t + "attn.qkv.w16", None, M, 512, 1536)
                 else:
                     qkv = self._ln_gemm_sh(tok, t + "norm1.weight", t + "norm1.bias", 1e-5, t + "attn.qkv.w16", None, M, 1536)
@@ -393,7 +415,7 @@ class Engine:
                 tok = self._gemm_sh(att, t + "attn.proj.w16", t + "attn.proj.bias", M, 512, 512, res=tok)
                 h = self._ln_gemm_sh(tok, t + "norm2.weight", t + "norm2.bias", 1e-5, t + "mlp.fc1.w16", t + "mlp.fc1.bias", M, 2048, act=ACT_GELU, out_sh=True)
                 nxt = (f"t{i + 1}.norm1.weight", f"t{i + 1}.norm1.bias", 1e-5, True) if i < 5 else ("enc_norm.w", "enc_norm.b", 1e-6, False)
-                tok, normed = self._fc2_ln(h, t + "mlp.fc2.w16", t + "mlp.fc2.bias", M, tok, nxt)
+                tok, normed, pending = self._fc2_ln(h, t + "mlp.fc2.w16", t + "mlp.fc2.bias", M, tok, nxt)
                 continue
             y = self._ln(tok, t + "norm1.weight", t + "norm1.bias", M, 1e-5)
             q = self._gemm(y, t + "attn.q.weight", None, M, 512, 512)
@@ -404,7 +426,13 @@ class Engine:
             y = self._ln(tok, t + "norm2.weight", t + "norm2.bias", M, 1e-5)
             h = self._gemm(y, t + "mlp.fc1.weight", t + "mlp.fc1.bias", M, 512, 2048, act=ACT_GELU)
             tok = self._gemm(h, t + "mlp.fc2.weight", t + "mlp.fc2.bias", M, 2048, 512, res=tok)
-        tok = normed if (sh and normed is not None) else self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
+        if sh and pending is not None:                                 # the last fc2's K slices: sum + bias + residual + encoder_norm in one kernel
+            parts, S, bkey, res_tok = pending
+            tok_sum, tok = new(M, 512), new(M, 512)
+            _lib.check(lib.omni_splitk_reduce_ln512(_p(parts), S, _p(self.w[bkey]), _p(res_tok), _p(tok_sum), _p(self.w["enc_norm.w"]), _p(self.w["enc_norm.b"]),
+                                                    ctypes.c_float(1e-6), _p(tok), 0, M, self._s), "reduce+ln")
+        else:
+            tok = normed if (sh and normed is not None) else self._ln(tok, "enc_norm.w", "enc_norm.b", M, 1e-6)
         _lib.check((lib.omni_add_hw_sh if sh else lib.omni_add_hw_f32)(_p(layer4), _p(tok), M, P32 * P32, 512, self._s), "token bias")
         # ---- decoder (:270-302); torch.cat is the two-source form of the conv
         up = self._up(layer4, M, P32, P32, 512, P16, P16)

@@ -1011,10 +1011,19 @@ def test_engine_switches_are_result_neutral():
     net_it.load_state_dict(make_state_dict(42, 18, True))
     rgb = torch.rand((3, 3, 128, 256), generator=torch.Generator().manual_seed(31)).to(DEV)
     one = rgb[:1].contiguous()
-    defaults = {k: getattr(Engine, k) for k in ("fuse_up", "tail_chunk", "front_chunk", "fold_point_feat", "rows_gemm", "fuse_ln", "fuse_fc2_ln")}
+    defaults = {k: getattr(Engine, k) for k in ("fuse_up", "tail_chunk", "front_chunk", "fold_point_feat", "rows_gemm", "fuse_ln", "fuse_fc2_ln", "fc2_slices")}
     ref, ref1, ref_it = net(rgb, confidence=True).clone(), net(one, confidence=True).clone(), net_it(rgb, 2)[-1].clone()
     try:
-        for name, value, exact in (("fuse_ln", False, True), ("fuse_fc2_ln", False, True), ("fuse_up", False, True), ("tail_chunk", 1, True), ("tail_chunk", 2, True), ("front_chunk", 1, True),
+        # a lone panorama's fc2 in K slices (summed by the next kernel) is another K summation order: rounding only; the LayerNorm fusion is exact beside it
+        Engine.fc2_slices = 1
+        unsliced1 = net(one, confidence=True).clone()
+        assert (unsliced1 - ref1).abs().max().item() < 2e-5 and torch.equal(net(rgb, confidence=True), ref)
+        Engine.fuse_ln = False
+        assert torch.equal(net(one, confidence=True), unsliced1) and torch.equal(net(rgb, confidence=True), ref)
+        Engine.fuse_ln, Engine.fc2_slices = defaults["fuse_ln"], 2
+        assert (net(one, confidence=True) - ref1).abs().max().item() < 2e-5
+        Engine.fc2_slices = defaults["fc2_slices"]
+        for name, value, exact in (("fuse_fc2_ln", False, True), ("fuse_up", False, True), ("tail_chunk", 1, True), ("tail_chunk", 2, True), ("front_chunk", 1, True),
                                    ("fold_point_feat", False, False), ("rows_gemm", False, False)):
             setattr(Engine, name, value)
             out, out1, out_it = net(rgb, confidence=True), net(one, confidence=True), net_it(rgb, 2)[-1]

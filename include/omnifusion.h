@@ -217,6 +217,14 @@ int omni_conv2d_sh_f16x3_post_ws(const void* src1, const void* src2, const void*
                                  const void* res, void* dst, int fmt, int M, int H, int W, int C1, int C2, int Cout,
                                  int KH, int KW, int stride, int pad, int act, int splitk, float* ws, size_t ws_bytes,
                                  const float* post, size_t post_elems, omni_stream_t stream);
+/* EXPERIMENTAL (round 6): Winograd F(2x2, 3x3) for the 3x3 stride-1 pad-1 convolutions of small images (model/spherical_model.py:122-143, layer3 / layer4 /
+ * de_conv0: Conv3d (3,3,1) + BatchNorm3d + ReLU) — 16 matrix products per 2 x 2 output tile instead of 36.  omni_wino_input_sh: x SH [M,H,W,C] (H, W even) ->
+ * V SH [16][M*H/2*W/2][C] = B^T d B per tile.  omni_conv3x3_wino_sh_f16x3: dst = act(conv3x3(x) + bias + res) from V and wt16 = the f16x3 split of
+ * [Cout][16*C] (k = p*C + c) holding (G g G^T)[p]; multiply stage and output transform in one kernel (conv_sh_kernel<.., WINO>); splitk in {1,2,4} divides the
+ * sixteen positions (ws: splitk * M*H*W * Cout floats).  Equal to omni_conv2d_sh_f16x3_ws up to rounding, not bit for bit. */
+int omni_wino_input_sh(const void* src, void* V, int M, int H, int W, int C, omni_stream_t stream);
+int omni_conv3x3_wino_sh_f16x3(const void* V, const void* wt16, const float* bias, const void* res, void* dst, int fmt,
+                               int M, int H, int W, int C, int Cout, int act, int splitk, float* ws, size_t ws_bytes, omni_stream_t stream);
 int omni_sh_from_f32(const float* src, void* dst, size_t n, omni_stream_t stream);
 int omni_sh_to_f32(const void* src, float* dst, size_t n, omni_stream_t stream);
 /* Range guard of the SH format: values with |x| > 65504 (the fp16 range) are SATURATED when an activation is split, and a

@@ -33,7 +33,7 @@ EXPORTS = [
     "omni_add_hw_f32", "omni_add_period_f32", "omni_token_pack_f32", "omni_layernorm512_f32",
     "omni_attention_f32", "omni_heads_f32", "omni_mlp_points_f32",
     "omni_conv2d_nhwc_f16x3_ws", "omni_conv2d_sh_f16x3_ws", "omni_conv2d_sh_f16x3_post_ws", "omni_gemm_rows_sh_f16x3", "omni_gemm_rows_ln_sh_f16x3", "omni_gemm_rows_pack", "omni_conv3x3_up2_sh_f16x3", "omni_conv3x3_up2_heads_sh_f16x3", "omni_up2_heads_scratch_bytes", "omni_heads_pack_f16x3", "omni_sh_from_f32", "omni_sh_to_f32", "omni_sh_overflow",
-    "omni_stem_sh", "omni_stem_sh_f16x3", "omni_maxpool3x3s2_sh", "omni_upsample_bilinear_sh", "omni_add_hw_sh", "omni_add_period_sh", "omni_layernorm512_sh", "omni_gemm_sh_f16x3_ln512_ws", "omni_gemm_rows_slices_sh_f16x3", "omni_gemm_rows_ln_parts_sh_f16x3", "omni_splitk_reduce_ln512", "omni_attention_qkv_sh",
+    "omni_stem_sh", "omni_stem_sh_f16x3", "omni_maxpool3x3s2_sh", "omni_upsample_bilinear_sh", "omni_add_hw_sh", "omni_add_period_sh", "omni_layernorm512_sh", "omni_gemm_sh_f16x3_ln512_ws", "omni_gemm_rows_slices_sh_f16x3", "omni_gemm_rows_ln_parts_sh_f16x3", "omni_splitk_reduce_ln512", "omni_wino_input_sh", "omni_conv3x3_wino_sh_f16x3", "omni_attention_qkv_sh",
     "omni_conv2d_splitk_plan", "omni_conv2d_nhwc_f32_ws",
     "omni_masked_median_f32", "omni_depth_metrics_f32",
     "omni_png_info", "omni_png_decode", "omni_png_decode_batch", "omni_zlib_inflate", "omni_png_checksums",

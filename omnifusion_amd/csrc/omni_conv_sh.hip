@@ -111,6 +111,7 @@ struct ShConvArgs {
     int wt_major;                            // 1: an XCD's contiguous block range walks tile_m fastest — it owns a range of OUTPUT-CHANNEL tiles and touches only their weights (conv_sh_kernel)
     int epi_lds;                             // 1: SH epilogues through an LDS transposition (16-byte pieces), OMNI_CONV_EPI_LDS
     int splitk; float* ws;                   // >1: blockIdx.y owns a K range, raw fp32 partial sums to ws[y][rows][Cout]
+    int wino_th, wino_tw, wino_pix;          // WINO kernels: tiles per image (H/2, W/2) and output pixels M*H*W (rows = tiles, Ho / Wo = the image)
     const float* post; unsigned post_rows;   // fp32 [post_rows][Cout] added AFTER the activation, row index modulo post_rows (layer1 + point_feat), or null
 };
 
@@ -280,10 +281,22 @@ __device__ __forceinline__ void splitk_finish(f4v v, size_t o, const float* __re
 //      group B:  b_{k-1} | mfma(k-1)      | a_k | reads(k)   wait  | b_k | mfma(k)    ...
 //      loaders:  wait(stage k landed) | b_{k-1} | issue stage k+NST-1 -> the slot of stage k-1 (B's reads of it ended in front of b_{k-1}) | a_k | ...
 // Same pieces, same LDS image, same fragments, same order of the matrix instructions on every accumulator: same bits.
-template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0, bool PP = false>           // NST stages in flight (the step loop is unrolled by it)
+//
+// WINO (round 6, experimental): the multiply stage AND the output transform of Winograd F(2x2, 3x3).  The "image" is the transformed input V [16 positions][tiles][C]
+// (omni_wino_input_sh), a row of the GEMM is a 2 x 2 output TILE, the K order is (position p, 32-channel group) — sixteen taps whose pixel offset is p * tiles —,
+// the weights are U_p = (G g G^T)[p] in the ordinary f16x3 split.  A wave (32 tiles x 32 channels: TM = TN = 1) keeps the four outputs of its tiles in registers:
+// when a position's last K-step has been issued, M_p = acc + 2^-11 acc1 is folded into Y[i][j] += A^T[i][xi] A^T[j][nu] M_p (coefficients 0 / +1 / -1) and the
+// accumulators start the next position from zero — 16 matrix products per four output pixels instead of 36.  splitk divides the POSITIONS.
+__constant__ float wino_coef[16][4] = {                        // [p = 4 xi + nu][o = 2 i + j] = A^T[i][xi] * A^T[j][nu],  A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]
+    {1, 0, 0, 0}, {1, 1, 0, 0}, {1, -1, 0, 0}, {0, -1, 0, 0},
+    {1, 0, 1, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {0, -1, 0, -1},
+    {1, 0, -1, 0}, {1, 1, -1, -1}, {1, -1, -1, 1}, {0, -1, 0, 1},
+    {0, 0, -1, 0}, {0, 0, -1, -1}, {0, 0, -1, 1}, {0, 0, 0, 1}};
+template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0, bool PP = false, bool WINO = false>           // NST stages in flight (the step loop is unrolled by it)
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs a)
 {
     static_assert(!PP || (NL > 0 && WM * WN == 8 && NST >= 3), "ping-pong: eight matrix waves (two per SIMD) + loader waves, three stages");
+    static_assert(!WINO || (PP && BM / WM == 32 && BN / WN == 32), "Winograd: the ping-pong kernel with 32 x 32 wave tiles");
     constexpr int NW = WM * WN, LW = NL > 0 ? NL : NW, RPP = 8 * LW;   // matrix waves; waves that issue DMA; tile rows covered by one DMA pass of the block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;         // 32x32 tiles per wave (waves WM x WN)
     constexpr int APASS = BM / RPP, BPASS = BN / RPP, LPS = APASS + BPASS;
@@ -325,6 +338,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
     for (int i = 0; i < APASS; ++i) {
         const int r = row0 + rl + RPP * i;
         vmask[i] = 0; pix[i] = 0;
+        if constexpr (WINO) {
+            if ((NL == 0 || loader) && r < a.rows) { pix[i] = r; vmask[i] = 0xffffu; }      // row = tile; tap p = position: offset p * tiles (a.W), always "inside"
+        } else
         if ((NL == 0 || loader) && r < a.rows) {
             const int hw = a.Ho * a.Wo;
             const int m = r / hw, rem = r - m * hw;
@@ -461,7 +477,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
                 ((ks + S < ks_end ? lstep(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
             }(std::make_integer_sequence<int, NST - 1>());
             pbarrier();                                           // b_{n-1}
-            if (a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) __syncthreads();    // (the barrier in front of the LDS epilogue)
+            if (!WINO && a.splitk <= 1 && a.dst_sh && !a.res_f32 && !a.post && a.epi_lds) __syncthreads();    // (the barrier in front of the LDS epilogue)
             return;
         }
         // ---- a loader wave's K loop: my pieces of stage ks have landed -> barrier (everybody's have; the matrix waves are done with stage
@@ -526,6 +542,31 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
                     }
             if constexpr (OMNI_PP_PRIO) __builtin_amdgcn_s_setprio(0);
         };
+        f16v Y[WINO ? 4 : 1];
+        int wino_g = 0, wino_p = ks_begin / (G > 0 ? G : 1);        // K-steps issued of the current position; the position
+        if constexpr (WINO) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) Y[o] = (f16v)(0.0f);
+        }
+        auto wino_fold = [&]() {                                     // behind a K-step's matrix instructions: the position's last?  fold it into the four outputs
+            if constexpr (WINO) {
+                if (++wino_g < G) return;
+                wino_g = 0;
+                f16v m;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m[e] = fmaf(acc1[0][0][e], 4.8828125e-4f, acc[0][0][e]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float c = wino_coef[wino_p][o];            // (wave-uniform: a scalar load)
+                    if (c != 0.0f) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) Y[o][e] = fmaf(c, m[e], Y[o][e]);
+                    }
+                }
+                acc[0][0] = (f16v)(0.0f); acc1[0][0] = (f16v)(0.0f);
+                ++wino_p;
+            }
+        };
         pbarrier();                                                  // b_{-1}: stage ks_begin has landed
         if (!grp_b) {
             auto stepa = [&](int ks, auto slot_c) {
@@ -535,6 +576,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
                 pbarrier();                                          // a_k
                 if (wave == 0 && ks - ks_begin < 28) cstamp(9 + 4 * (ks - ks_begin));
                 mfmas();
+                wino_fold();
                 if (wave == 0 && ks - ks_begin < 28) cstamp(10 + 4 * (ks - ks_begin));
                 pbarrier();                                          // b_k
             };
@@ -552,6 +594,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
                 reads(slot_c);
                 pbarrier();                                          // b_k
                 mfmas();
+                wino_fold();
             };
             int ks = ks_begin;
             for (; ks + NST - 1 < ks_end; ks += NST) {
@@ -561,6 +604,30 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_sh_kernel(ShConvArgs
             [&]<int... S>(std::integer_sequence<int, S...>) {
                 ((ks + S < ks_end ? stepb(ks + S, std::integral_constant<int, S>()) : (void)0), ...);
             }(std::make_integer_sequence<int, NST - 1>());
+        }
+        if constexpr (WINO) {
+            // ---- the four output pixels of my tile (column lane & 31): tile -> (image, tile row, tile column) -> pixel (2 ty + i, 2 tx + j); per register quad the
+            // lane holds four consecutive channels, as in every other epilogue.  splitk > 1 (the positions were divided): raw partial outputs to the workspace,
+            // pixel-major like every split-K launch, for sh_splitk_reduce_kernel.
+            const int tl = row0 + wm * (BM / WM) + (lane & 31);
+            if (tl >= a.rows) return;
+            const int per_img = a.wino_th * a.wino_tw, m = tl / per_img, rem = tl - m * per_img, ty = rem / a.wino_tw, tx = rem - ty * a.wino_tw;
+            const int cj[1] = {col0 + wn * (BN / WN)};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const size_t r = ((size_t)m * a.Ho + 2 * ty + (o >> 1)) * a.Wo + 2 * tx + (o & 1);
+                if (a.splitk > 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f4v v; v.x = Y[o][4 * q]; v.y = Y[o][4 * q + 1]; v.z = Y[o][4 * q + 2]; v.w = Y[o][4 * q + 3];
+                        *reinterpret_cast<f4v*>(a.ws + ((size_t)blockIdx.y * a.wino_pix + r) * a.Cout + cj[0] + 8 * q + 4 * (lane >> 5)) = v;
+                    }
+                } else {
+                    const f16v ea[1] = {Y[o]}, eb[1] = {(f16v)(0.0f)};
+                    epilogue_row<1, 2>(ea, eb, a, r, cj, lane, a.dst_sh != 0);
+                }
+            }
+            return;
         }
     }
     auto step = [&](int ks, auto slot_c) {
@@ -1811,6 +1878,38 @@ __global__ __launch_bounds__(512) void gemm_rows_ln_sh_kernel(RowsGemmArgs a, co
     else          act_store4<false>(a.dst, o, v);
 }
 
+// Winograd F(2x2, 3x3) input transform: V[p = 4 xi + nu][tile][c] = (B^T d B)[xi][nu], d = the 4 x 4 window (rows 2 ty - 1 .. 2 ty + 2, columns 2 tx - 1 .. 2 tx + 2,
+// zeros outside the image) of tile (m, ty, tx); B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].  SH in, SH out; one thread per (tile, 4 channels).
+__global__ __launch_bounds__(256) void wino_input_sh_kernel(const void* __restrict__ src, void* __restrict__ V, int M, int H, int W, int C, size_t nt)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int cq = C >> 2;
+    if (i >= nt * cq) return;
+    const size_t tl = i / cq;
+    const int c = (int)(i - tl * cq) * 4;
+    const int tw = W >> 1, th = H >> 1;
+    const int m = (int)(tl / (size_t)(th * tw)), rem = (int)(tl - (size_t)m * th * tw), ty = rem / tw, tx = rem - ty * tw;
+    f4v d[4][4];
+#pragma unroll
+    for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_) {
+            const int y = 2 * ty - 1 + a_, x = 2 * tx - 1 + b_;
+            d[a_][b_] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? act_load4<true>(src, (((size_t)m * H + y) * W + x) * C + c) : (f4v)(0.0f);
+        }
+    f4v u[4][4];                                                  // B^T d
+#pragma unroll
+    for (int b_ = 0; b_ < 4; ++b_) { u[0][b_] = d[0][b_] - d[2][b_]; u[1][b_] = d[1][b_] + d[2][b_]; u[2][b_] = d[2][b_] - d[1][b_]; u[3][b_] = d[1][b_] - d[3][b_]; }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {                              // (B^T d) B
+        const f4v v0 = u[xi][0] - u[xi][2], v1 = u[xi][1] + u[xi][2], v2 = u[xi][2] - u[xi][1], v3 = u[xi][1] - u[xi][3];
+        act_store4<true>(V, ((size_t)(4 * xi + 0) * nt + tl) * C + c, v0);
+        act_store4<true>(V, ((size_t)(4 * xi + 1) * nt + tl) * C + c, v1);
+        act_store4<true>(V, ((size_t)(4 * xi + 2) * nt + tl) * C + c, v2);
+        act_store4<true>(V, ((size_t)(4 * xi + 3) * nt + tl) * C + c, v3);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NST = 3, int NL = 0>
 void launch_sh(ShConvArgs a, hipStream_t s)
 {
@@ -1909,7 +2008,7 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     // 1 auto | 0 never | 2 always)
     a.wt_major = omni_options().conv_wt_major == 2 || (omni_options().conv_wt_major == 1 &&
                  (long long)Cout * ksteps * 128 > (long long)M * H * W * (C1 + C2) * 4) ? 1 : 0;
-    a.post = post; a.post_rows = 1;
+    a.post = post; a.post_rows = 1; a.wino_th = a.wino_tw = a.wino_pix = 0;
     if (post) {
         if (Cout <= 0 || post_elems == 0 || post_elems % (size_t)Cout || post_elems / (size_t)Cout > 0x7fffffffull)
             OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv2d_sh: the post-activation addend must hold whole rows of Cout channels");
@@ -1991,6 +2090,51 @@ static int conv2d_sh_impl(const void* src1, const void* src2, const void* wt16, 
     return OMNI_OK;
 }
 
+// ---- Winograd F(2x2, 3x3) for 3x3 stride-1 pad-1 convolutions of small images (EXPERIMENTAL, round 6; conv_sh_kernel<.., WINO>)
+// omni_wino_input_sh: src SH [M,H,W,C] (H, W even) -> V SH [16][M * H/2 * W/2][C].
+extern "C" int omni_wino_input_sh(const void* src, void* V, int M, int H, int W, int C, omni_stream_t stream)
+{
+    if (!src || !V) OMNI_FAIL(OMNI_ERR_INVALID, "omni_wino_input_sh: null pointer");
+    if (M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || C % 32) OMNI_FAIL(OMNI_ERR_INVALID, "omni_wino_input_sh: even image sides, channels a multiple of 32");
+    const size_t nt = (size_t)M * (H / 2) * (W / 2), n = nt * (C / 4);
+    if (16 * nt * C * 4 >= (1ull << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_wino_input_sh: the transformed tensor must stay under 2 GiB (32-bit buffer offsets)");
+    hipLaunchKernelGGL(wino_input_sh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, V, M, H, W, C, nt);
+    OMNI_HIP(hipGetLastError());
+    return OMNI_OK;
+}
+
+// dst [M,H,W,Cout] = act(conv3x3(x) + bias + res) from V = omni_wino_input_sh(x) and wt16 = the f16x3 split (omni_conv2d's weight format) of the matrix
+// [Cout][16 * C], k = p * C + c, holding U_p = (G g G^T)[p] (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]).  fmt as omni_conv2d_sh_f16x3_ws (bit 0: dst SH; bit 1: res fp32).
+// splitk in {1, 2, 4}: the sixteen positions divided over that many blocks per tile, partial outputs to ws (splitk * M*H*W * Cout floats) and
+// sh_splitk_reduce_kernel.  Cout % 64 == 0, C % 32 == 0.  Equal to the direct convolution up to rounding (measured 1e-6 against float64, tools/winograd_proto.py).
+extern "C" int omni_conv3x3_wino_sh_f16x3(const void* V, const void* wt16, const float* bias, const void* res, void* dst, int fmt,
+                                          int M, int H, int W, int C, int Cout, int act, int splitk, float* ws, size_t ws_bytes, omni_stream_t stream)
+{
+    if (!V || !wt16 || !dst) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_wino_sh: null pointer");
+    if (M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || C % 32 || Cout <= 0 || Cout % 64) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_wino_sh: even image sides, C % 32 == 0, Cout % 64 == 0");
+    if (splitk != 1 && splitk != 2 && splitk != 4) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_wino_sh: splitk must be 1, 2 or 4 (it divides the sixteen positions)");
+    const long long nt = (long long)M * (H / 2) * (W / 2), pix = (long long)M * H * W;
+    if (16 * nt * C * 4 >= (1ll << 31) || (long long)Cout * 16 * C * 4 >= (1ll << 31) || pix >= (1ll << 31)) OMNI_FAIL(OMNI_ERR_UNSUPPORTED, "omni_conv3x3_wino_sh: an operand of 2 GiB or more");
+    if (splitk > 1 && (!ws || ws_bytes < (size_t)splitk * pix * Cout * sizeof(float))) OMNI_FAIL(OMNI_ERR_INVALID, "omni_conv3x3_wino_sh: split workspace too small");
+    ShConvArgs a;
+    a.src1 = V; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = res; a.dst = dst; a.dst_sh = fmt & 1; a.res_f32 = (fmt >> 1) & 1;
+    a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.wt_major = 0; a.epi_lds = 0;
+    a.M = 1; a.H = 16; a.W = (int)nt; a.C1 = C; a.C2 = 0; a.Cout = Cout; a.KH = 16; a.KW = 1; a.stride = 1; a.pad = 0; a.act = act;
+    a.Ho = H; a.Wo = W; a.rows = (int)nt; a.splitk = splitk; a.ws = ws; a.post = nullptr; a.post_rows = 1;
+    a.wino_th = H / 2; a.wino_tw = W / 2; a.wino_pix = (int)pix;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (int)((nt + 127) / 128) * (Cout / 64);
+    hipLaunchKernelGGL((conv_sh_kernel<128, 64, 4, 2, 3, 4, true, true>), dim3(tiles, splitk), dim3(64 * 12), 0, s, a);
+    OMNI_HIP(hipGetLastError());
+    if (splitk > 1) {
+        const size_t n4 = (size_t)pix * Cout / 4;
+        hipLaunchKernelGGL(sh_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, bias, res, dst,
+                           n4, Cout, splitk, (size_t)pix * Cout, act, a.dst_sh, a.res_f32);
+        OMNI_HIP(hipGetLastError());
+    }
+    return OMNI_OK;
+}
+
 // dst = act(conv3x3(pad 1)(bilinear 2x up-sampling of src) + bias): F.interpolate(scale 2, align_corners=False) + ConvBnReLU of the
 // decoder (model/spherical_model.py:279-301) in one kernel (conv3x3_halo_sh_kernel<.., UP2>).  src SH [M, Hl, Wl, C], dst [M, 2Hl, 2Wl, Cout]
 // SH (fmt bit 0) or fp32; needs 2Wl % 32 == 0, 2Hl % 4 == 0 (OMNI_ERR_UNSUPPORTED otherwise: run omni_upsample_bilinear_sh +
@@ -2011,7 +2155,7 @@ extern "C" int omni_conv3x3_up2_sh_f16x3(const void* src, const void* wt16, cons
     a.dbg = omni_debug_bits("OMNI_CONV_DBG");
 #endif
     a.M = M; a.H = H; a.W = W; a.C1 = C; a.C2 = 0; a.Cout = Cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = act;
-    a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
+    a.Ho = H; a.Wo = W; a.rows = M * H * W; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1; a.wino_th = a.wino_tw = a.wino_pix = 0;
     const int grid = M * (H / 4) * (W / HT_W);
     if (C == 32 && Cout == 32 && omni_options().conv_up2_persist) {    // de_conv4_0: resident weights, one persistent block of 8 waves per CU
         hipLaunchKernelGGL(conv3x3_up2_g1_kernel<false>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(512), 0, (hipStream_t)stream, a, grid, HeadsArgs{nullptr, nullptr});
@@ -2047,7 +2191,7 @@ extern "C" int omni_conv3x3_up2_heads_sh_f16x3(const void* src, const void* wt16
     a.src1 = src; a.src2 = nullptr; a.wt = wt16; a.bias = bias; a.res = nullptr; a.dst = nullptr; a.dst_sh = 0; a.res_f32 = 0;
     a.dbg = 0; a.noxcd = omni_options().conv_noxcd; a.wt_major = 0; a.epi_lds = 0;
     a.M = M; a.H = P; a.W = P; a.C1 = 32; a.C2 = 0; a.Cout = 32; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.act = OMNI_ACT_RELU;
-    a.Ho = P; a.Wo = P; a.rows = M * P * P; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1;
+    a.Ho = P; a.Wo = P; a.rows = M * P * P; a.splitk = 1; a.ws = nullptr; a.post = nullptr; a.post_rows = 1; a.wino_th = a.wino_tw = a.wino_pix = 0;
     const int grid = M * (P / 4) * (P / HT_W);
     hipLaunchKernelGGL(conv3x3_up2_g1_kernel<true>, dim3(grid < 256 ? (grid + 7) / 8 * 8 : 256), dim3(64 * (4 + OMNI_G1_PW)), 0, (hipStream_t)stream, a, grid, HeadsArgs{heads_w16f, scratch});
     OMNI_HIP(hipGetLastError());

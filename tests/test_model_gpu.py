@@ -482,6 +482,61 @@ def test_fc2_second_pass_with_layernorm_gives_the_bits_of_the_two_calls(rows, S,
     assert lib.omni_gemm_sh_f16x3_ln512_ws(_p(XS), _p(W16), _p(B), _p(R), _p(tok1), _p(LG), _p(LB), ctypes.c_float(eps), _p(y1), 0, rows, K, S, _p(ws), ctypes.c_size_t(16), _stream()) != 0
 
 
+@pytest.mark.parametrize("cfg", [(144, 8, 8, 256, 256, True, 1), (9, 8, 8, 64, 128, False, 0), (36, 4, 4, 128, 64, True, 3), (5, 16, 12, 32, 64, False, 1)])
+def test_winograd_experimental_path_vs_torch(cfg):
+    """Round 6, experimental (not used by the model): Winograd F(2x2, 3x3) — omni_wino_input_sh (B^T d B per 2 x 2 output tile) + omni_conv3x3_wino_sh_f16x3 (the
+    sixteen per-position f16x3 products AND the output transform A^T M A in one kernel, conv_sh_kernel<.., WINO>; positions undivided / in 2 / in 4 with the
+    split-K second pass) against a float64 torch convolution (+ bias, residual, ReLU), and the input transform against its definition."""
+    L, lib = _lib()
+    from omnifusion_amd.model._engine import split_weights_f16x3
+    M, H, W, C, Co, use_res, fmt_bits = cfg
+    g = torch.Generator().manual_seed(60 + M)
+    x = torch.relu(torch.randn(M, H, W, C, generator=g))
+    w = torch.randn(Co, C, 3, 3, generator=g) / np.sqrt(9 * C)
+    b, res = torch.randn(Co, generator=g), torch.randn(M, H, W, Co, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    if use_res:
+        ref = ref + res.double()
+    ref = F.relu(ref)
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    n32 = lambda t: ctypes.c_size_t(t.numel())
+
+    def to_sh(t):
+        o = torch.empty_like(t)
+        assert lib.omni_sh_from_f32(_p(t), _p(o), n32(t), _stream()) == 0
+        return o
+    X = to_sh(x.to(DEV))
+    NT = M * (H // 2) * (W // 2)
+    V = torch.empty(16 * NT * C, device=DEV)
+    assert lib.omni_wino_input_sh(_p(X), _p(V), M, H, W, C, _stream()) == 0, lib.omni_last_error()
+    vf = torch.empty_like(V)
+    assert lib.omni_sh_to_f32(_p(V), _p(vf), n32(V), _stream()) == 0
+    tiles = F.pad(x.permute(0, 3, 1, 2).double(), (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)           # [M, C, th, tw, 4, 4]
+    v64 = torch.einsum("ij,mcyxjk,lk->ilmyxc", BT, tiles, BT).reshape(16, NT, C)
+    assert (vf.cpu().double().reshape(16, NT, C) - v64).abs().max().item() < 4e-6
+    U = torch.einsum("ij,ocjk,lk->oilc", G, w.double(), G).reshape(Co, 16 * C)                              # [Cout][p * C + c]
+    UW = split_weights_f16x3(U.float().contiguous()).to(DEV)
+    B_, R = b.to(DEV), res.to(DEV)
+    if use_res and not (fmt_bits & 2):
+        R = to_sh(R)
+    ws = torch.empty(4 * M * H * W * Co, device=DEV)
+    outs = []
+    for sk in (1, 2, 4):
+        o = torch.full((M, H, W, Co), float("nan"), device=DEV)
+        rc = lib.omni_conv3x3_wino_sh_f16x3(_p(V), _p(UW), _p(B_), _p(R) if use_res else None, _p(o), fmt_bits, M, H, W, C, Co, 1, sk, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+        assert rc == 0, lib.omni_last_error()
+        if fmt_bits & 1:
+            of = torch.empty_like(o)
+            assert lib.omni_sh_to_f32(_p(o), _p(of), n32(o), _stream()) == 0
+            o = of
+        assert (o.cpu().double() - ref).abs().max().item() < 1e-5, sk
+        outs.append(o)
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-5 and (outs[0] - outs[2]).abs().max().item() < 1e-5
+    assert lib.omni_conv3x3_wino_sh_f16x3(_p(V), _p(UW), _p(B_), None, _p(o), 0, M, H, W, C, Co, 1, 3, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()) != 0      # 3 does not divide 16
+    assert lib.omni_wino_input_sh(_p(X), _p(V), M, 7, W, C, _stream()) != 0                                                                                      # odd image side
+
+
 def test_small_ops_vs_torch():
     L, lib = _lib()
     g = torch.Generator().manual_seed(2)

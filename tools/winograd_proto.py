@@ -83,3 +83,23 @@ def one_position():
 t_dir, t_m1, t_p = timeit(direct), timeit(multiply1), timeit(one_position)
 print(f"us: direct {t_dir:.1f} | multiply stage as ONE launch over 16 x {NT} rows {t_m1:.1f} | one position's GEMM [{NT} x {C}] . [{C} x {Co}] alone {t_p:.1f} (x 16 = {16 * t_p:.0f}: sixteen short launches are no option)")
 print(f"the multiply stage alone is {t_dir / t_m1:.2f}x the direct convolution's speed; with its fp32 products written ({16 * NT * Co * 4 / 1e6:.1f} MB) and V read ({16 * NT * C * 4 / 1e6:.1f} MB)")
+
+# ---- the product's own Winograd path (round 6, experimental): omni_wino_input_sh + omni_conv3x3_wino_sh_f16x3 (multiply stage and output transform in one kernel)
+UW = split_weights_f16x3(U.permute(1, 0, 2).reshape(Co, 16 * C).float().contiguous()).cuda()      # [Cout][16 * C], k = p * C + c
+VP = torch.empty(16 * NT * C, device="cuda")
+assert lib.omni_wino_input_sh(P(XS), P(VP), M, H, W, C, S()) == 0
+vb = torch.empty(16 * NT * C, device="cuda"); assert lib.omni_sh_to_f32(P(VP), P(vb), ctypes.c_size_t(vb.numel()), S()) == 0
+print(f"input transform kernel vs torch: max |d| {(vb.reshape(16, NT, C) - V).abs().max().item():.2e}")
+R = torch.relu(torch.randn(M, H, W, Co, generator=g)).cuda(); RS = sh(R)
+ref_r = torch.relu(ref + R.cpu().double())
+ws = torch.empty(4 * M * H * W * Co, device="cuda")
+for sk in (1, 2, 4):
+    o = torch.full((M, H, W, Co), float("nan"), device="cuda")
+    def wino(): assert lib.omni_conv3x3_wino_sh_f16x3(P(VP), P(UW), P(B), P(RS), P(o), 1, M, H, W, C, Co, 1, sk, P(ws), ctypes.c_size_t(ws.numel() * 4), S()) == 0, lib.omni_last_error()
+    wino(); torch.cuda.synchronize()
+    of = torch.empty_like(o); assert lib.omni_sh_to_f32(P(o), P(of), ctypes.c_size_t(o.numel()), S()) == 0
+    print(f"product Winograd (+ residual, ReLU, SH out), positions split {sk}: max |d| vs float64 {(of.cpu().double() - ref_r).abs().max().item():.3e} | kernel(s) {timeit(wino):.1f} us")
+def intr(): assert lib.omni_wino_input_sh(P(XS), P(VP), M, H, W, C, S()) == 0
+o2 = torch.empty(M, H, W, Co, device="cuda")
+def direct_r(): assert lib.omni_conv2d_sh_f16x3_ws(P(XS), None, P(W16), P(B), P(RS), P(o2), 1, M, H, W, C, 0, Co, 3, 3, 1, 1, 1, 1, None, ctypes.c_size_t(0), S()) == 0
+print(f"input transform kernel {timeit(intr):.1f} us | direct convolution (+ residual, ReLU, SH out) {timeit(direct_r):.1f} us")

@@ -34,7 +34,9 @@ for k, d in sorted(agg.items(), key=lambda kv: -sum(dur[kv[0]])):
     mt = re.search(r"(\w+<[^>]*>)", k)
     if mt:
         key = mt.group(1).replace(" ", "")
-        if key.startswith("conv_sh_kernel<"): key = key.replace(",true>", ",PP>").replace(",false>", ">")     # (the last template argument: the ping-pong schedule)
+        if key.startswith("conv_sh_kernel<"):                   # <BM,BN,WM,WN,NST,NL,PP,WINO>: the two flags by name, defaults dropped
+            ar = key[len("conv_sh_kernel<"):-1].split(",")
+            key = "conv_sh_kernel<" + ",".join(ar[:6] + (["PP"] if len(ar) > 6 and ar[6] == "true" else []) + (["WINO"] if len(ar) > 7 and ar[7] == "true" else [])) + ">"
         busy[key] = m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)
     print("%s avg_us=%.1f n=%d   mfma_busy=%.1f%%" % (k, sum(dur[k]) / len(dur[k]), len(dur[k]), 100 * m("SQ_VALU_MFMA_BUSY_CYCLES") / (m("GRBM_GUI_ACTIVE") / 8 * 1024)))
     for c, v in sorted(d.items()):
